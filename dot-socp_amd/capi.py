@@ -1,0 +1,111 @@
+"""ctypes binding of lib/libdotsocp.so (include/dotsocp.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import of
+the first symbol, and every compute entry point returns DOTSOCP_ENODEVICE without a GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdotsocp.so")
+
+i64 = ctypes.c_longlong
+dbl = ctypes.c_double
+vp = ctypes.c_void_p
+
+
+class DotsocpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdotsocp error {code}: {msg}")
+        self.code = code
+
+
+class Problem(ctypes.Structure):
+    _fields_ = [("dim", ctypes.c_int), ("weighted", ctypes.c_int),
+                ("ny", i64), ("nx", i64), ("nt", i64),
+                ("D", dbl), ("E", dbl), ("cScale", dbl), ("dScale", dbl),
+                ("normc", dbl), ("normd", dbl)]
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("tau", dbl), ("sigma", dbl), ("tol", dbl), ("maxit", i64),
+                ("ifCheckStepByStep", ctypes.c_int), ("checkPrimDualFeas", ctypes.c_int),
+                ("scaling", ctypes.c_int), ("time_limit", dbl)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("sigma", dbl), ("sigma_internal", dbl), ("cScale", dbl), ("dScale", dbl),
+                ("times", dbl * 7), ("iters", i64), ("hist_len", i64), ("stopped", ctypes.c_int)]
+
+
+F_PHI, F_Q, F_ALPHA, F_Z, F_BETA, F_C, F_WEIGHT = range(7)
+
+# every symbol include/dotsocp.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dotsocp_last_error": (ctypes.c_char_p, []),
+    "dotsocp_version": (ctypes.c_char_p, []),
+    "dotsocp_device_count": (ctypes.c_int, []),
+    "dotsocp_proj_soc": (ctypes.c_int, [vp, vp, i64, i64]),
+    "dotsocp_bfd": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl, dbl]),
+    "dotsocp_bfd_conj": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl]),
+    "dotsocp_bfd1d": (ctypes.c_int, [vp, vp, i64, i64, dbl, dbl]),
+    "dotsocp_bfd_conj1d": (ctypes.c_int, [vp, vp, i64, i64, dbl]),
+    "dotsocp_oper_poisson": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl]),
+    "dotsocp_dctn": (ctypes.c_int, [vp, i64, i64, i64, ctypes.c_int]),
+    "dotsocp_proj_soc_dev": (ctypes.c_int, [vp, vp, i64, i64, vp]),
+    "dotsocp_bfd_dev": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl, dbl, vp]),
+    "dotsocp_bfd_conj_dev": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl, vp]),
+    "dotsocp_create": (vp, [ctypes.POINTER(Problem), ctypes.c_int, ctypes.c_int]),
+    "dotsocp_destroy": (None, [vp]),
+    "dotsocp_rccl_unique_id": (ctypes.c_int, [vp]),
+    "dotsocp_attach_rccl": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int]),
+    "dotsocp_slab_range": (ctypes.c_int, [i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
+    "dotsocp_upload": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "dotsocp_download": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "dotsocp_begin": (ctypes.c_int, [vp, ctypes.POINTER(Opts)]),
+    "dotsocp_run": (ctypes.c_int, [vp, i64, ctypes.POINTER(i64)]),
+    "dotsocp_finish": (ctypes.c_int, [vp, ctypes.POINTER(Result)]),
+    "dotsocp_get_history": (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    "dotsocp_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),
+    "dotsocp_kernel_time": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.POINTER(dbl), ctypes.POINTER(i64)]),
+    "dotsocp_synchronize": (ctypes.c_int, [vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdotsocp.so (built by `make -C dot-socp_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise DotsocpError(code, lib().dotsocp_last_error().decode())
+
+
+def fptr(a):
+    """Pointer to a Fortran/C-contiguous float64 numpy array (no copy)."""
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not (a.flags.f_contiguous or a.flags.c_contiguous):
+        raise ValueError("expected a contiguous float64 numpy array")
+    return a.ctypes.data
+
+
+def slab_range(nt, world, rank):
+    t0, t1 = i64(), i64()
+    check(lib().dotsocp_slab_range(nt, world, rank, ctypes.byref(t0), ctypes.byref(t1)))
+    return t0.value, t1.value

@@ -1,0 +1,96 @@
+// Device-side helpers shared by cone.hip, stencil.hip and kkt.hip.
+#pragma once
+#include "common.h"
+
+namespace dotsocp {
+
+#define TILE_Y 64
+#define TILE_X 4
+
+// Row projection onto {x1 >= ||x_2..K||}; literal restatement of mexProjSoc's arithmetic
+// (SURVEY.md 8a a1): n = ||x_2..K||, c = clamp((x1/n + 1)/2, 0, 1) with NaN passing through,
+// x_j <- c x_j, x_1 <- (c >= 1) ? x_1 : c n.
+template <int K>
+__device__ __forceinline__ void proj_row(double (&v)[K]) {
+    double nn = v[1] * v[1];
+#pragma unroll
+    for (int j = 2; j < K; ++j) nn += v[j] * v[j];
+    const double n = sqrt(nn);
+    double c = (v[0] / n + 1.0) * 0.5;
+    c = (c > 1.0) ? 1.0 : c;
+    c = (c < 0.0) ? 0.0 : c;
+#pragma unroll
+    for (int j = 1; j < K; ++j) v[j] = c * v[j];
+    v[0] = (c >= 1.0) ? v[0] : c * n;
+}
+
+// The four staggered edge values around cell column (y, x) at time layer tt (pre-multiplied
+// by sf); edges outside the domain contribute exact zeros (mexBFd never writes those slots).
+struct EdgeQuad {
+    double xm, xp, ym, yp;
+};
+
+__device__ __forceinline__ EdgeQuad load_edges(const Grid &g, const double *__restrict__ q, i64 y, i64 x,
+                                               i64 tt, double sf) {
+    EdgeQuad e;
+    const double *bx = q + g.offBx + g.bxLayer * tt;
+    const double *by = q + g.offBy + g.byLayer * tt;
+    e.xm = (x >= 1) ? sf * bx[y + g.ny * (x - 1)] : 0.0;
+    e.xp = (x <= g.nx - 2) ? sf * bx[y + g.ny * x] : 0.0;
+    e.ym = (y >= 1) ? sf * by[(y - 1) + (g.ny - 1) * x] : 0.0;
+    e.yp = (y <= g.ny - 2) ? sf * by[y + (g.ny - 1) * x] : 0.0;
+    return e;
+}
+
+__device__ __forceinline__ void build_z2(double (&v)[10], double q0, const EdgeQuad &a, const EdgeQuad &b,
+                                         double s, double dF) {
+    v[0] = dF - s * q0;
+    v[1] = a.xm; v[2] = a.xp; v[3] = b.xm; v[4] = b.xp;
+    v[5] = a.ym; v[6] = a.yp; v[7] = b.ym; v[8] = b.yp;
+    v[9] = dF + s * q0;
+}
+
+// Adjoint gather for one staggered edge.  `w(j, cell)` is supplied by a functor so the same
+// code serves w = z (operator level), w = z + beta (q-step) and w = beta (KKT).
+template <class W>
+__device__ __forceinline__ double gather_bx(const Grid &g, const W &w, i64 y, i64 xe, i64 tl,
+                                            const double *__restrict__ tail_bx) {
+    double acc = 0.0;
+    if (tl < g.ncl) {
+        acc += w(1, y + g.ny * ((xe + 1) + g.nx * tl));
+        acc += w(2, y + g.ny * (xe + g.nx * tl));
+    }
+    if (tl >= 1) {
+        acc += w(3, y + g.ny * ((xe + 1) + g.nx * (tl - 1)));
+        acc += w(4, y + g.ny * (xe + g.nx * (tl - 1)));
+    } else if (!g.first) {
+        acc += tail_bx[y + g.ny * xe];
+    }
+    return acc;
+}
+
+template <class W>
+__device__ __forceinline__ double gather_by(const Grid &g, const W &w, i64 ye, i64 x, i64 tl,
+                                            const double *__restrict__ tail_by) {
+    double acc = 0.0;
+    if (tl < g.ncl) {
+        acc += w(5, (ye + 1) + g.ny * (x + g.nx * tl));
+        acc += w(6, ye + g.ny * (x + g.nx * tl));
+    }
+    if (tl >= 1) {
+        acc += w(7, (ye + 1) + g.ny * (x + g.nx * (tl - 1)));
+        acc += w(8, ye + g.ny * (x + g.nx * (tl - 1)));
+    } else if (!g.first) {
+        acc += tail_by[ye + (g.ny - 1) * x];
+    }
+    return acc;
+}
+
+struct WPlain {
+    const double *w;
+    i64 Nz;
+    __device__ __forceinline__ double operator()(int j, i64 cell) const { return w[j * Nz + cell]; }
+};
+
+
+}  // namespace dotsocp

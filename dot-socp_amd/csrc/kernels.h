@@ -1,0 +1,88 @@
+// Host-side launchers of the gfx950 kernels (definitions in *.hip).
+#pragma once
+#include "common.h"
+
+namespace dotsocp {
+
+// Scalars of one inPALM iteration (solver_socp_inPALM.m:53-59,96-97,194-215).
+struct LoopCoef {
+    double s;      // scaleBF = E / D
+    double sf;     // s / sqrt(2)
+    double dF;     // scaleD = E / dScale
+    double at, ax, ay;   // D/ht, D/hx, D/hy  (entries of D * grad, initialize.m:67-87)
+    double tau;
+    double c1, c2;       // (1+) 2 s^2, (1+) s^2  -- diagonal of I + s^2 F*B*BF (oper_q.m:14-23); without the 1 when weighted
+    double dinv1, dinv2; // 1/c1, 1/c2 (unweighted diagQInv)
+};
+
+// Number of partial-sum slots produced by the KKT kernels.
+enum {
+    S_Q2 = 0, S_Z2, S_APHI2, S_ALPHA2, S_BETA2, S_FBBETA2, S_PRIM1, S_PRIM2, S_DUAL1, S_DUAL2,
+    S_COMPLEM, S_DOTCOMP, S_RHO2, S_RHOFQ2, S_MRHOB, S_M2, S_RHOB2, S_QALPHA, S_CPHI, S_PHI2,
+    S_COUNT
+};
+
+struct KktCoef {
+    double sigma;
+    double kappa;      // sigma * cScale * D      (compute_kkt_dot_complement.m:2)
+    double dsD;        // dScale / D
+    double dsE;        // dScale / E
+};
+
+// ---------------- cone.hip ----------------
+int launch_proj_soc(double *out, const double *in, i64 M, i64 K, hipStream_t st);
+int launch_bfd(const Grid &g, double *z, const double *q, double s, double dF, hipStream_t st);
+int launch_bfd_conj(const Grid &g, double *q, const double *w, double s, hipStream_t st);
+// z = Pi_Q(B F q + d - beta), B F q + d regenerated from q on the fly (solver_socp_inPALM.m:199)
+int launch_cone_proj(const Grid &g, const LoopCoef &c, const double *q, const double *beta, double *z,
+                     hipStream_t st);
+// beta += tau * (z - (B F q + d))    (solver_socp_inPALM.m:212-215)
+int launch_beta_update(const Grid &g, const LoopCoef &c, const double *q, const double *z, double *beta,
+                       hipStream_t st);
+// partial adjoint sums of the LAST owned cell layer for the right neighbour (time-slab mode)
+int launch_gather_tail(const Grid &g, const double *z, const double *beta, double *tail_bx, double *tail_by,
+                       hipStream_t st);
+
+// ---------------- stencil.hip ----------------
+// rhs = A'(w.*q - alpha) + c   (solver_socp_inPALM.m:194, solver_wsocp_inPALM.m:200)
+int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *alpha, const double *cvec,
+               const double *weight, const double *u0_prev, double *rhs, hipStream_t st);
+// q-step + alpha update (solver_socp_inPALM.m:204-206,211,214; solver_wsocp_inPALM.m:210-217)
+int launch_qstep(const Grid &g, const LoopCoef &c, const double *phi, const double *z, const double *beta,
+                 const double *weight, const double *tail_bx, const double *tail_by, double *q,
+                 double *alpha, hipStream_t st);
+// u0 = w.*q0 - alpha0 of the last owned cell layer (halo for the right neighbour's rhs)
+int launch_u0_tail(const Grid &g, const double *q, const double *alpha, const double *weight, double *out,
+                   hipStream_t st);
+int launch_scale(double *x, i64 n, double mul, double div, hipStream_t st);   // x = x * mul / div
+
+// ---------------- kkt.hip ----------------
+struct KktWork {
+    double *partials;   // [maxBlocks][S_COUNT]
+    i64 maxBlocks;
+    double *sums;       // [S_COUNT] device
+};
+// Halo layers from the LEFT neighbour slab's last cell (all nullptr on the first slab):
+// alpha0, w.*alpha0, and the partial adjoint sums of beta (columns 4,5 / 8,9).
+struct KktHalo {
+    const double *a0_prev, *a0w_prev, *btail_bx, *btail_by;
+};
+i64 kkt_partials_needed(const Grid &g);
+int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double *phi, const double *q,
+               const double *alpha, const double *z, const double *beta, const double *cvec,
+               const double *weight, const KktHalo &halo, const KktWork &w, hipStream_t st);
+
+// ---------------- dct.hip ----------------
+struct DctPlan;   // twiddles / dense matrices for one axis length
+DctPlan *dct_plan_create(i64 n);
+void dct_plan_destroy(DctPlan *p);
+// Orthonormal DCT-II (inverse=0) / DCT-III (inverse=1) along one axis of an [n0][n1][n2] array
+// (n0 fastest), src -> dst.  axis = 0, 1 or 2.  src == dst is allowed for power-of-two lengths only.
+int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis,
+                    int inverse, hipStream_t st);
+// data[i] /= kscale * lambda(i)  with lambda the DCT eigenvalues of initialize_FFTkernel.m:6-15
+// for global dims (ny, nx, nt); the local block covers x in [x0, x0+nxl) (pencil mode) and all y, t.
+int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl, double kscale,
+                           const double *cy, const double *cx, const double *ct, hipStream_t st);
+
+}  // namespace dotsocp

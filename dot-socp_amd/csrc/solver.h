@@ -1,0 +1,94 @@
+// Device-resident inPALM/ALG2 loop state (B1 boundary of include/dotsocp.h).
+#pragma once
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace dotsocp {
+
+struct Slab {
+    Grid g;
+    double *phi = nullptr;      // NphiAlloc (owned nodes + halo layer)
+    double *q = nullptr;        // NqAlloc
+    double *alpha = nullptr;    // NqAlloc
+    double *z = nullptr;        // 10 * Nz
+    double *beta = nullptr;     // 10 * Nz
+    double *c = nullptr;        // Nphi
+    double *weight = nullptr;   // NqAlloc (weighted only)
+    double *w0 = nullptr, *w1 = nullptr;   // Poisson work arrays
+    // halos received from the LEFT neighbour (nullptr on the first slab)
+    double *u0_prev = nullptr, *tail_bx = nullptr, *tail_by = nullptr;
+    double *a0_prev = nullptr, *a0w_prev = nullptr, *btail_bx = nullptr, *btail_by = nullptr;
+    // staging for what this slab sends to the RIGHT neighbour
+    double *send_plane = nullptr, *send_bx = nullptr, *send_by = nullptr;
+    KktWork kw{};
+};
+
+enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_COUNT };
+
+struct Solver {
+    dotsocp_problem prob{};
+    int device = 0;
+    i64 ny = 0, nx = 0, nt = 0;     // internal dims (1-D problems: ny = nx1d, nx = 1)
+    hipStream_t stream = nullptr;
+    std::vector<Slab> slabs;
+    DctPlan *py = nullptr, *px = nullptr, *pt = nullptr;
+    double *cy = nullptr, *cx = nullptr, *ct = nullptr;   // DCT eigenvalue tables (device)
+    double *h_sums = nullptr;       // pinned host buffer [S_COUNT]
+
+    // ---- loop state (mirrors solver_socp_inPALM.m:11-135) ----
+    bool begun = false, finished = false, stopped = false;
+    dotsocp_opts opts{};
+    bool checkPrimDualFeas = true;
+    double time_limit = 3600.0;
+    double sigma = 1.0, sigmaScale = 1.0;
+    double cScale = 1.0, dScale = 1.0, D = 1.0, E = 1.0;
+    double norm_c = 0.0, norm_d = 0.0;
+    double h = 1.0;
+    int rescale = 0, use_feasOrg = 0;
+    double maxFeas = 0.0, relGap = 0.0, tol_feasOrg = 0.0;
+    double lastSigmaIt = 0.0;
+    i64 it = 0;
+    LoopCoef lc{};
+    std::vector<double> hist_kkt, hist_time, hist_iter, hist_gap;   // kkt stored row-wise (7 per entry)
+    std::chrono::steady_clock::time_point t_begin;
+    double elapsed_prev = 0.0;
+
+    // ---- profiling (HIP events on the launch stream) ----
+    bool profiling = false;
+    struct Pending { hipEvent_t a, b; int phase; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    double phase_ms[PH_COUNT] = {0};
+    i64 phase_launches[PH_COUNT] = {0};
+
+    ~Solver();
+    int init(const dotsocp_problem *p, int device, int nslabs);
+    int upload(int field, const double *host);
+    int download(int field, double *host);
+    int begin(const dotsocp_opts *o);
+    int run(i64 n_iters, i64 *done);
+    int finish(dotsocp_result *res);
+
+    // internals
+    int step(bool *brk);
+    int rescale_block();
+    int phase_phi();
+    int phase_z();
+    int phase_q();
+    int phase_mult();
+    int kkt_sums(double *S);
+    int kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk);
+    int scale_state(double a_mul, double a_div, double q_div, bool with_c);
+    void update_coef();
+    double elapsed() const;
+    void prof_begin(int phase);
+    void prof_end(int phase);
+    int prof_flush();
+    int poisson(Slab &s, const double *rhs, double *out);
+    i64 field_len(int field, bool local) const;
+};
+
+}  // namespace dotsocp

@@ -1,0 +1,622 @@
+// Host side of the device-resident inPALM / ALG2 loop.  The scalar control flow (sigma rule,
+// rescale triggers, KKT ratios, stop test) restates socp/dot2d/algorithms/solver_socp_inPALM.m
+// (and solver_wsocp_inPALM.m for the weighted variant) line by line; all array work is done by the
+// kernels of cone.hip / stencil.hip / dct.hip / kkt.hip on one HIP stream.
+#include "solver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace dotsocp {
+
+thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+template <class T>
+static int dmalloc(T **p, i64 n) {
+    *p = nullptr;
+    if (n <= 0) n = 1;
+    DS_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)n));
+    return 0;
+}
+
+static void dfree(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+Solver::~Solver() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &s : slabs) {
+        dfree(s.phi); dfree(s.q); dfree(s.alpha); dfree(s.z); dfree(s.beta); dfree(s.c); dfree(s.weight);
+        dfree(s.w0); dfree(s.w1);
+        dfree(s.u0_prev); dfree(s.tail_bx); dfree(s.tail_by);
+        dfree(s.a0_prev); dfree(s.a0w_prev); dfree(s.btail_bx); dfree(s.btail_by);
+        dfree(s.send_plane); dfree(s.send_bx); dfree(s.send_by);
+        dfree(s.kw.partials); dfree(s.kw.sums);
+    }
+    dct_plan_destroy(py); dct_plan_destroy(px); dct_plan_destroy(pt);
+    dfree(cy); dfree(cx); dfree(ct);
+    if (h_sums) (void)hipHostFree(h_sums);
+    for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : event_pool) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+static int make_eig_table(double **dev, i64 n) {
+    // (2 (n-1)^2) (1 - cos(pi k / n))   -- initialize_FFTkernel.m:6-8
+    std::vector<double> t((size_t)n);
+    const double pi = 3.14159265358979323846;
+    for (i64 k = 0; k < n; ++k) t[k] = (2.0 * (double)(n - 1) * (double)(n - 1)) * (1.0 - cos(pi * (double)k / (double)n));
+    DS_CHECK(dmalloc(dev, n));
+    DS_HIP(hipMemcpy(*dev, t.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dotsocp_slab_range_impl(i64 nt, int world, int rank, i64 *t0, i64 *t1) {
+    // nodes are dealt as evenly as possible; the last slab owns one cell layer fewer than nodes
+    const i64 base = nt / world, rem = nt % world;
+    const i64 a = rank * base + std::min<i64>(rank, rem);
+    const i64 b = a + base + (rank < rem ? 1 : 0);
+    *t0 = a;
+    *t1 = b;
+    return 0;
+}
+
+int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
+    DS_ARG(p != nullptr, "prob is NULL");
+    DS_ARG(p->dim == 1 || p->dim == 2, "prob.dim must be 1 or 2");
+    DS_ARG(p->nt >= 2 && p->nx >= 1, "grid too small");
+    prob = *p;
+    device = dev;
+    if (p->dim == 1) { ny = p->nx; nx = 1; } else { ny = p->ny; nx = p->nx; }
+    nt = p->nt;
+    DS_ARG(ny >= 1 && nx >= 1, "grid too small");
+    DS_ARG(nslabs >= 1 && nslabs <= nt / 2, "nslabs must be in [1, nt/2]");
+    if (nslabs != 1) {
+        set_error("in-process multi-slab mode is not available in this build");
+        return DOTSOCP_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (libdotsocp has no CPU fallback)");
+        return DOTSOCP_ENODEVICE;
+    }
+    DS_ARG(dev >= 0 && dev < ndev, "device ordinal out of range");
+    DS_HIP(hipSetDevice(dev));
+    DS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * S_COUNT));
+    py = dct_plan_create(ny);
+    px = dct_plan_create(nx);
+    pt = dct_plan_create(nt);
+    if (!py || !px || !pt) {
+        set_error("DCT plan allocation failed");
+        return DOTSOCP_EHIP;
+    }
+    DS_CHECK(make_eig_table(&cy, ny));
+    DS_CHECK(make_eig_table(&cx, nx));
+    DS_CHECK(make_eig_table(&ct, nt));
+    slabs.resize(nslabs);
+    for (int r = 0; r < nslabs; ++r) {
+        Slab &s = slabs[r];
+        i64 t0, t1;
+        dotsocp_slab_range_impl(nt, nslabs, r, &t0, &t1);
+        s.g.set(ny, nx, nt, t0, t1 - t0);
+        const Grid &g = s.g;
+        DS_CHECK(dmalloc(&s.phi, g.NphiAlloc));
+        DS_CHECK(dmalloc(&s.q, g.NqAlloc));
+        DS_CHECK(dmalloc(&s.alpha, g.NqAlloc));
+        DS_CHECK(dmalloc(&s.z, 10 * g.Nz));
+        DS_CHECK(dmalloc(&s.beta, 10 * g.Nz));
+        DS_CHECK(dmalloc(&s.c, g.Nphi));
+        DS_CHECK(dmalloc(&s.w0, g.Nphi));
+        DS_CHECK(dmalloc(&s.w1, g.Nphi));
+        if (prob.weighted) DS_CHECK(dmalloc(&s.weight, g.NqAlloc));
+        DS_HIP(hipMemsetAsync(s.phi, 0, sizeof(double) * g.NphiAlloc, stream));
+        DS_HIP(hipMemsetAsync(s.q, 0, sizeof(double) * g.NqAlloc, stream));
+        DS_HIP(hipMemsetAsync(s.alpha, 0, sizeof(double) * g.NqAlloc, stream));
+        DS_HIP(hipMemsetAsync(s.z, 0, sizeof(double) * 10 * g.Nz, stream));
+        DS_HIP(hipMemsetAsync(s.beta, 0, sizeof(double) * 10 * g.Nz, stream));
+        DS_HIP(hipMemsetAsync(s.c, 0, sizeof(double) * g.Nphi, stream));
+        s.kw.maxBlocks = kkt_partials_needed(g);
+        DS_CHECK(dmalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT));
+        DS_CHECK(dmalloc(&s.kw.sums, S_COUNT));
+    }
+    DS_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// upload / download (host pointers hold the GLOBAL field in the reference layout)
+// --------------------------------------------------------------------------------------
+static const int k1dCols[6] = {0, 5, 6, 7, 8, 9};   // 1-D cone columns inside the 10-plane layout
+
+i64 Solver::field_len(int field, bool) const {
+    const i64 Nz = ny * nx * (nt - 1), Nphi = ny * nx * nt;
+    const i64 Nq = Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt;
+    switch (field) {
+        case DOTSOCP_F_PHI: case DOTSOCP_F_C: return Nphi;
+        case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: return Nq;
+        case DOTSOCP_F_Z: case DOTSOCP_F_BETA: return Nz * (prob.dim == 1 ? 6 : 10);
+        default: return -1;
+    }
+}
+
+int Solver::upload(int field, const double *host) {
+    DS_ARG(host != nullptr, "host pointer is NULL");
+    DS_ARG(field_len(field, false) >= 0, "unknown field");
+    DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "weight uploaded to an unweighted problem");
+    DS_HIP(hipSetDevice(device));
+    const i64 NzG = ny * nx * (nt - 1);
+    const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * nt;
+    for (auto &s : slabs) {
+        const Grid &g = s.g;
+        switch (field) {
+            case DOTSOCP_F_PHI:
+                DS_HIP(hipMemcpyAsync(s.phi, host + g.plane * g.t0, sizeof(double) * g.Nphi, hipMemcpyHostToDevice, stream));
+                break;
+            case DOTSOCP_F_C:
+                DS_HIP(hipMemcpyAsync(s.c, host + g.plane * g.t0, sizeof(double) * g.Nphi, hipMemcpyHostToDevice, stream));
+                break;
+            case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: {
+                double *d = field == DOTSOCP_F_Q ? s.q : (field == DOTSOCP_F_ALPHA ? s.alpha : s.weight);
+                DS_HIP(hipMemcpyAsync(d, host + g.plane * g.t0, sizeof(double) * g.Nz, hipMemcpyHostToDevice, stream));
+                if (g.bxLayer > 0)
+                    DS_HIP(hipMemcpyAsync(d + g.offBx, host + bxG + g.bxLayer * g.t0, sizeof(double) * g.bxLayer * g.ntl,
+                                          hipMemcpyHostToDevice, stream));
+                if (g.byLayer > 0)
+                    DS_HIP(hipMemcpyAsync(d + g.offBy, host + byG + g.byLayer * g.t0, sizeof(double) * g.byLayer * g.ntl,
+                                          hipMemcpyHostToDevice, stream));
+                break;
+            }
+            case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
+                double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
+                const int K = prob.dim == 1 ? 6 : 10;
+                if (prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, stream));
+                for (int j = 0; j < K; ++j) {
+                    const int pj = prob.dim == 1 ? k1dCols[j] : j;
+                    DS_HIP(hipMemcpyAsync(d + pj * g.Nz, host + j * NzG + g.plane * g.t0, sizeof(double) * g.Nz,
+                                          hipMemcpyHostToDevice, stream));
+                }
+                break;
+            }
+        }
+    }
+    DS_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Solver::download(int field, double *host) {
+    DS_ARG(host != nullptr, "host pointer is NULL");
+    DS_ARG(field_len(field, false) >= 0, "unknown field");
+    DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
+    DS_HIP(hipSetDevice(device));
+    const i64 NzG = ny * nx * (nt - 1);
+    const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * nt;
+    for (auto &s : slabs) {
+        const Grid &g = s.g;
+        switch (field) {
+            case DOTSOCP_F_PHI:
+                DS_HIP(hipMemcpyAsync(host + g.plane * g.t0, s.phi, sizeof(double) * g.Nphi, hipMemcpyDeviceToHost, stream));
+                break;
+            case DOTSOCP_F_C:
+                DS_HIP(hipMemcpyAsync(host + g.plane * g.t0, s.c, sizeof(double) * g.Nphi, hipMemcpyDeviceToHost, stream));
+                break;
+            case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: {
+                const double *d = field == DOTSOCP_F_Q ? s.q : (field == DOTSOCP_F_ALPHA ? s.alpha : s.weight);
+                DS_HIP(hipMemcpyAsync(host + g.plane * g.t0, d, sizeof(double) * g.Nz, hipMemcpyDeviceToHost, stream));
+                if (g.bxLayer > 0)
+                    DS_HIP(hipMemcpyAsync(host + bxG + g.bxLayer * g.t0, d + g.offBx, sizeof(double) * g.bxLayer * g.ntl,
+                                          hipMemcpyDeviceToHost, stream));
+                if (g.byLayer > 0)
+                    DS_HIP(hipMemcpyAsync(host + byG + g.byLayer * g.t0, d + g.offBy, sizeof(double) * g.byLayer * g.ntl,
+                                          hipMemcpyDeviceToHost, stream));
+                break;
+            }
+            case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
+                const double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
+                const int K = prob.dim == 1 ? 6 : 10;
+                for (int j = 0; j < K; ++j) {
+                    const int pj = prob.dim == 1 ? k1dCols[j] : j;
+                    DS_HIP(hipMemcpyAsync(host + j * NzG + g.plane * g.t0, d + pj * g.Nz, sizeof(double) * g.Nz,
+                                          hipMemcpyDeviceToHost, stream));
+                }
+                break;
+            }
+        }
+    }
+    DS_HIP(hipStreamSynchronize(stream));
+    // after finish(): var.alpha = sigma * alpha, var.beta = sigma * beta  (solver_socp_inPALM.m:335-336)
+    if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) {
+        const i64 n = field_len(field, false);
+        for (i64 i = 0; i < n; ++i) host[i] = sigma * host[i];
+    }
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// profiling helpers
+// --------------------------------------------------------------------------------------
+void Solver::prof_begin(int phase) {
+    if (!profiling) return;
+    Pending p;
+    p.phase = phase;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    p.a = get();
+    p.b = get();
+    (void)hipEventRecord(p.a, stream);
+    pending.push_back(p);
+}
+
+void Solver::prof_end(int phase) {
+    if (!profiling) return;
+    for (auto it2 = pending.rbegin(); it2 != pending.rend(); ++it2)
+        if (it2->phase == phase) { (void)hipEventRecord(it2->b, stream); break; }
+}
+
+int Solver::prof_flush() {
+    if (!profiling || pending.empty()) return 0;
+    DS_HIP(hipStreamSynchronize(stream));
+    for (auto &p : pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            phase_ms[p.phase] += ms;
+            phase_launches[p.phase] += 1;
+        }
+        event_pool.push_back(p.a);
+        event_pool.push_back(p.b);
+    }
+    pending.clear();
+    return 0;
+}
+
+double Solver::elapsed() const {
+    return elapsed_prev + std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+}
+
+// --------------------------------------------------------------------------------------
+// begin: solver_socp_inPALM.m:11-135
+// --------------------------------------------------------------------------------------
+void Solver::update_coef() {
+    lc.s = E / D;                       // scaleBF (:58)
+    lc.sf = lc.s / sqrt(2.0);
+    lc.dF = E / dScale;                 // scaleD (:59,183)
+    const double ht = 1.0 / (double)(nt - 1);
+    lc.at = D * (1.0 / ht);             // D .* grad, entries 1/ht (initialize.m:68; solver_dotsocp2d.m:338)
+    lc.ax = (nx > 1) ? D * (1.0 / (1.0 / (double)(nx - 1))) : 0.0;
+    lc.ay = (ny > 1) ? D * (1.0 / (1.0 / (double)(ny - 1))) : 0.0;
+    lc.tau = opts.tau;
+    const double tmp = (E / D) * (E / D);   // oper_q.m:14
+    if (prob.weighted) { lc.c1 = 2.0 * tmp; lc.c2 = tmp; }
+    else { lc.c1 = 1.0 + 2.0 * tmp; lc.c2 = 1.0 + tmp; }
+    lc.dinv1 = 1.0 / lc.c1;
+    lc.dinv2 = 1.0 / lc.c2;
+}
+
+int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
+    for (auto &s : slabs) {
+        const Grid &g = s.g;
+        if (with_c) DS_CHECK(launch_scale(s.c, g.Nphi, a_mul, a_div, stream));
+        DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, stream));
+        DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, stream));
+        if (q_div != 1.0) {
+            DS_CHECK(launch_scale(s.q, g.NqAlloc, 1.0, q_div, stream));
+            DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, stream));
+        }
+    }
+    return 0;
+}
+
+int Solver::begin(const dotsocp_opts *o) {
+    DS_ARG(o != nullptr, "opts is NULL");
+    DS_ARG(o->maxit >= 0, "opts.maxit < 0");
+    DS_ARG(o->sigma > 0, "opts.sigma must be positive");
+    if (begun) { set_error("begin() called twice"); return DOTSOCP_ESTATE; }
+    DS_HIP(hipSetDevice(device));
+    opts = *o;
+    checkPrimDualFeas = (o->checkPrimDualFeas < 0) ? !prob.weighted : (o->checkPrimDualFeas != 0);   // :20-24 / wsocp :25-29
+    time_limit = (o->time_limit > 0) ? o->time_limit : 3600.0;                                        // :26-30
+    sigma = o->sigma;
+    lastSigmaIt = -INFINITY;
+    cScale = prob.cScale; dScale = prob.dScale; D = prob.D; E = prob.E;                                // :54-59
+    use_feasOrg = 0;
+    tol_feasOrg = 5 * o->tol;
+    rescale = o->scaling ? 1 : 0;                                                                      // :64-68
+    maxFeas = INFINITY; relGap = INFINITY;
+    h = 1.0 / ((double)nx * (double)ny * (double)nt);                                                  // :84
+    norm_c = prob.normc; norm_d = prob.normd;                                                          // :100-101
+    update_coef();
+    // alpha /= sigma, beta /= sigma, c /= sigma                                                       // :102-104
+    DS_CHECK(scale_state(1.0, sigma, 1.0, true));
+    sigmaScale = 1.0;
+    it = 0;
+    stopped = false;
+    hist_kkt.clear(); hist_time.clear(); hist_iter.clear(); hist_gap.clear();
+    for (int i = 0; i < PH_COUNT; ++i) { phase_ms[i] = 0; phase_launches[i] = 0; }
+    begun = true;
+    elapsed_prev = 0.0;
+    t_begin = std::chrono::steady_clock::now();
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// the four steps of one iteration
+// --------------------------------------------------------------------------------------
+int Solver::poisson(Slab &s, const double *rhs, double *out) {
+    // phi = idctn(dctn(rhs) ./ kernel), kernel = D^2 * initialize_FFTkernel  (:96,194)
+    const Grid &g = s.g;
+    double *a = s.w0, *b = s.w1;
+    DS_CHECK(launch_dct_axis(py, rhs, b, g.ny, g.nx, g.ntl, 0, 0, stream));
+    DS_CHECK(launch_dct_axis(px, b, a, g.ny, g.nx, g.ntl, 1, 0, stream));
+    DS_CHECK(launch_dct_axis(pt, a, b, g.ny, g.nx, g.ntl, 2, 0, stream));
+    DS_CHECK(launch_spectral_divide(b, g.ny, g.nx, g.nt, 0, g.nx, D * D, cy, cx, ct, stream));
+    DS_CHECK(launch_dct_axis(pt, b, a, g.ny, g.nx, g.ntl, 2, 1, stream));
+    DS_CHECK(launch_dct_axis(px, a, b, g.ny, g.nx, g.ntl, 1, 1, stream));
+    DS_CHECK(launch_dct_axis(py, b, out, g.ny, g.nx, g.ntl, 0, 1, stream));
+    return 0;
+}
+
+int Solver::phase_phi() {
+    for (auto &s : slabs) {
+        prof_begin(PH_RHS);
+        DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, stream));
+        prof_end(PH_RHS);
+        prof_begin(PH_POISSON);
+        DS_CHECK(poisson(s, s.w0, s.phi));
+        prof_end(PH_POISSON);
+    }
+    return 0;
+}
+
+int Solver::phase_z() {
+    for (auto &s : slabs) {
+        prof_begin(PH_PROJ);
+        DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, stream));
+        prof_end(PH_PROJ);
+    }
+    return 0;
+}
+
+int Solver::phase_q() {
+    for (auto &s : slabs) {
+        prof_begin(PH_QSTEP);
+        DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
+        prof_end(PH_QSTEP);
+    }
+    return 0;
+}
+
+int Solver::phase_mult() {
+    for (auto &s : slabs) {
+        prof_begin(PH_BETA);
+        DS_CHECK(launch_beta_update(s.g, lc, s.q, s.z, s.beta, stream));
+        prof_end(PH_BETA);
+    }
+    return 0;
+}
+
+int Solver::kkt_sums(double *S) {
+    KktCoef k;
+    k.sigma = sigma;
+    k.kappa = sigma * cScale * D;
+    k.dsD = dScale / D;
+    k.dsE = dScale / E;
+    for (int i = 0; i < S_COUNT; ++i) S[i] = 0.0;
+    for (auto &s : slabs) {
+        KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
+        DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, stream));
+        DS_HIP(hipMemcpyAsync(h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+        DS_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i < S_COUNT; ++i) S[i] += h_sums[i];
+    }
+    return 0;
+}
+
+// solver_socp_inPALM.m:138-190
+int Solver::rescale_block() {
+    bool scaleYes = false;
+    double normPhis = 0, normAlps = 0;
+    auto norms = [&](double &nPhis, double &nAlps) -> int {
+        double S[S_COUNT];
+        DS_CHECK(kkt_sums(S));
+        const double sh = sqrt(h);
+        const double normPhi = sh * sqrt(S[S_PHI2]), normQ = sh * sqrt(S[S_Q2]), normZ = sh * sqrt(S[S_Z2]);
+        const double normAlpha = sigma * (sh * sqrt(S[S_ALPHA2])), normBeta = sigma * (sh * sqrt(S[S_BETA2]));
+        nPhis = std::max(std::max(normPhi, normQ), normZ);
+        nAlps = std::max(normAlpha, normBeta);
+        return 0;
+    };
+    if (rescale >= 3 && (it % 100) == 0) {
+        DS_CHECK(norms(normPhis, normAlps));
+        const double ratio = std::max(normAlps, normPhis) / std::min(normAlps, normPhis);
+        if (ratio > 1.2) scaleYes = true;
+    }
+    const bool first = (rescale == 1) && (maxFeas < 2e-2) && (it >= 10) && (relGap < 5e-2);
+    const bool second = (rescale == 2) && (maxFeas < 5e-3) && (it >= 50) && (relGap < 1e-2);
+    if (!(first || second || scaleYes)) return 0;
+    if (!scaleYes) DS_CHECK(norms(normPhis, normAlps));
+    const double dScale2 = normPhis, cScale2 = normAlps;
+    sigma = sigma * (cScale2 / dScale2);
+    norm_c = norm_c / cScale2;
+    if (!prob.weighted) norm_d = norm_d / dScale2;      // solver_wsocp_inPALM.m has no norm_d
+    // c, alpha, beta <- x * dScale2 / cScale2^2 ; q, z <- x / dScale2
+    DS_CHECK(scale_state(dScale2, cScale2 * cScale2, dScale2, true));
+    dScale = dScale2 * dScale;
+    cScale = cScale2 * cScale;
+    sigmaScale = sigmaScale * (cScale2 / dScale2);
+    update_coef();                                       // scaleD = E / dScale (:183); z2 is regenerated on the fly
+    rescale += 1;
+    return 0;
+}
+
+static bool if_adjust_sigma(double iter, double last_iter) {   // :361-379
+    const double passed = iter - last_iter;
+    if (iter < 20 && passed >= 3) return true;
+    if (iter < 50 && passed >= 6) return true;
+    if (iter < 100 && passed >= 10) return true;
+    if (iter < 200 && passed >= 15) return true;
+    if (iter < 500 && passed >= 25) return true;
+    return passed >= 40;
+}
+
+static const double kUpdateRule[11][2] = {   // :39-51
+    {1.1, 1.10}, {1.2, 1.15}, {1.5, 1.20}, {2, 1.26}, {2.5, 1.28}, {3.33, 1.32},
+    {5, 1.35}, {10, 1.40}, {20, 1.60}, {40, 1.80}, {50, 2.00}};
+
+static double get_factor(double xi) {   // adjust_lagrangianParam.m:49-60
+    double factor = 1.0;
+    for (int i = 0; i < 11; ++i) {
+        if (xi >= kUpdateRule[i][0]) factor = kUpdateRule[i][1];
+        else break;
+    }
+    return factor;
+}
+
+static void adjust_lagrangian_param(double &sigma, double xi, double &factor) {   // adjust_lagrangianParam.m:14-39
+    factor = 1.0;
+    if (xi >= 1) factor = get_factor(xi);
+    else if (xi < 1) factor = 1.0 / get_factor(1.0 / xi);
+    if (factor != 1.0) {
+        const double old = sigma;
+        sigma = std::max(std::min(sigma * factor, 1e3), 1e-3);
+        factor = sigma / old;
+    }
+}
+
+// solver_socp_inPALM.m:222-323
+int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
+    double S[S_COUNT];
+    prof_begin(PH_KKT);
+    DS_CHECK(kkt_sums(S));
+    prof_end(PH_KKT);
+    const double sh = sqrt(h);
+    auto nrm = [&](int i) { return sh * sqrt(S[i]); };
+    const double norm_q = nrm(S_Q2), norm_z = nrm(S_Z2), norm_Aphi = nrm(S_APHI2);
+    const double norm_alpha = sigma * nrm(S_ALPHA2), norm_beta = sigma * nrm(S_BETA2);
+    const double norm_FBbeta = sigma * nrm(S_FBBETA2);
+    const double primFea1 = nrm(S_PRIM1), primFea2 = nrm(S_PRIM2);
+    const double dualFea1 = sigma * nrm(S_DUAL1), dualFea2 = sigma * nrm(S_DUAL2);
+    const double complem = nrm(S_COMPLEM);
+    const double dotcomplem = nrm(S_DOTCOMP), normRho = nrm(S_RHO2), norm_rhoFq = nrm(S_RHOFQ2);
+    const double mRhoB = nrm(S_MRHOB), normM = nrm(S_M2), normRhoB = nrm(S_RHOB2);
+    const double kc = 1.0;
+    const double den2 = prob.weighted ? (norm_q + norm_z) : norm_d;        // wsocp :256,265
+    double org[7], res[5];
+    org[0] = primFea1 / (kc * D / dScale + norm_Aphi + norm_q);
+    org[1] = primFea2 / (kc * E / dScale + den2);
+    org[2] = dualFea1 / (kc / cScale + norm_c);
+    org[3] = complem / (kc * E / dScale + norm_z + norm_beta);
+    org[4] = dualFea2 / (kc / cScale / D + norm_FBbeta + norm_alpha);
+    org[5] = dotcomplem / (kc + normRho + norm_rhoFq);
+    org[6] = mRhoB / (kc + normM + normRhoB);
+    res[0] = primFea1 / (kc + norm_Aphi + norm_q);
+    res[1] = primFea2 / (kc + den2);
+    res[2] = dualFea1 / (kc + norm_c);
+    res[3] = complem / (kc + norm_z + norm_beta);
+    res[4] = dualFea2 / (kc + norm_FBbeta + norm_alpha);
+    const double priVal = (sigma * cScale * dScale * h) * S[S_QALPHA];
+    const double dualVal = (sigma * cScale * dScale * h) * S[S_CPHI];
+    const double pdGap = fabs(priVal - dualVal) / (1 + fabs(priVal) + fabs(dualVal));
+    for (int i = 0; i < 7; ++i) hist_kkt.push_back(org[i]);
+    hist_time.push_back(elapsed());
+    hist_iter.push_back((double)it);
+    hist_gap.push_back(pdGap);
+    // stop criterion (:287-290); stopCondition = [1,3,6,7] or [1,3,6] (:117-121)
+    double mstop = std::max(std::max(org[0], org[2]), org[5]);
+    if (checkPrimDualFeas) mstop = std::max(mstop, org[6]);
+    if (mstop < opts.tol || timed_out) {
+        *brk = true;
+        return 0;
+    }
+    const double maxRes = *std::max_element(res, res + 5);
+    if (maxRes < tol_feasOrg) use_feasOrg = 1;                              // :293-295
+    if (adjustSigmaYes) {                                                   // :298-316
+        lastSigmaIt = (double)it;
+        double resiPri, resiDual;
+        if (use_feasOrg) { resiPri = std::max(org[0], org[1]); resiDual = std::max(org[2], org[4]); }
+        else { resiPri = std::max(res[0], res[1]); resiDual = std::max(res[2], res[4]); }
+        double factor;
+        adjust_lagrangian_param(sigma, resiPri / resiDual, factor);
+        if (factor != 1.0) DS_CHECK(scale_state(1.0, factor, 1.0, true));
+    }
+    if (rescale > 0) {                                                      // :319-322
+        maxFeas = maxRes;
+        relGap = pdGap;
+    }
+    return 0;
+}
+
+int Solver::step(bool *brk) {
+    *brk = false;
+    it += 1;
+    DS_CHECK(rescale_block());
+    DS_CHECK(phase_phi());
+    DS_CHECK(phase_z());
+    DS_CHECK(phase_q());
+    DS_CHECK(phase_mult());
+    const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
+    const bool timed_out = elapsed() > time_limit;
+    if (opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out)        // :221
+        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
+    return 0;
+}
+
+int Solver::run(i64 n_iters, i64 *done) {
+    if (!begun || finished) { set_error("run() needs begin() and must precede finish()"); return DOTSOCP_ESTATE; }
+    DS_HIP(hipSetDevice(device));
+    i64 n = 0;
+    while (it < opts.maxit && !stopped) {
+        if (n_iters >= 0 && n >= n_iters) break;
+        bool brk = false;
+        DS_CHECK(step(&brk));
+        if (brk) stopped = true;
+        ++n;
+    }
+    DS_HIP(hipStreamSynchronize(stream));
+    DS_CHECK(prof_flush());
+    if (done) *done = n;
+    return 0;
+}
+
+int Solver::finish(dotsocp_result *res) {
+    if (!begun) { set_error("finish() before begin()"); return DOTSOCP_ESTATE; }
+    DS_HIP(hipSetDevice(device));
+    DS_HIP(hipStreamSynchronize(stream));
+    DS_CHECK(prof_flush());
+    finished = true;
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->sigma = sigma / sigmaScale;        // :357
+        res->sigma_internal = sigma;
+        res->cScale = cScale;
+        res->dScale = dScale;
+        // device time per step (HIP events) when profiling is on; Total_Time is host wall time
+        res->times[0] = (phase_ms[PH_RHS] + phase_ms[PH_POISSON]) * 1e-3;
+        res->times[1] = phase_ms[PH_PROJ] * 1e-3;
+        res->times[2] = phase_ms[PH_QSTEP] * 1e-3;
+        res->times[3] = phase_ms[PH_BETA] * 1e-3;
+        res->times[4] = phase_ms[PH_KKT] * 1e-3;
+        res->times[5] = elapsed();
+        res->times[6] = (double)it;
+        res->iters = it;
+        res->hist_len = (i64)hist_iter.size();
+        res->stopped = stopped ? 1 : 0;
+    }
+    return 0;
+}
+
+}  // namespace dotsocp

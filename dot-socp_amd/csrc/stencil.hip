@@ -1,0 +1,199 @@
+// Matrix-free staggered-gradient stencils of the loop: rhs = A'(w.*q - alpha) + c and the
+// q-step / alpha-update.  A = D * [Dt; Dx; Dy] are forward differences
+// (socp/dot2d/utils/initialize.m:35-39,67-87, scaled by D in solver_dotsocp2d.m:338);
+// summation orders follow the column/row order of the reference's sparse products
+//  so that results agree with the oracle to the last bit.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace dotsocp {
+
+static inline dim3 tile_grid(const Grid &g, i64 layers) {
+    return dim3((unsigned)((g.ny + TILE_Y - 1) / TILE_Y), (unsigned)((g.nx + TILE_X - 1) / TILE_X), (unsigned)layers);
+}
+
+// ---------------------------------------------------------------------------------------
+// rhs(y,x,t) = sum over the (up to) six staggered neighbours, Neumann: missing ones dropped
+// (solver_socp_inPALM.m:194; weighted: solver_wsocp_inPALM.m:200)
+// ---------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs(Grid g, LoopCoef c, const double *__restrict__ q,
+                                                         const double *__restrict__ alpha,
+                                                         const double *__restrict__ cvec,
+                                                         const double *__restrict__ weight,
+                                                         const double *__restrict__ u0_prev,
+                                                         double *__restrict__ rhs) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    const i64 tl = blockIdx.z;
+    if (y >= g.ny || x >= g.nx) return;
+    auto u = [&](i64 k) { return WEIGHTED ? weight[k] * q[k] - alpha[k] : q[k] - alpha[k]; };
+    const i64 node = y + g.ny * (x + g.nx * tl);
+    double r = 0.0;
+    // Dt' : cell t-1/2 enters with +D/ht, cell t+1/2 with -D/ht
+    if (tl >= 1)
+        r += c.at * u(node - g.plane);
+    else if (!g.first)
+        r += c.at * u0_prev[y + g.ny * x];
+    if (tl < g.ncl) r += (-c.at) * u(node);
+    // Dx'
+    const i64 bxo = g.offBx + g.bxLayer * tl;
+    if (x >= 1) r += c.ax * u(bxo + y + g.ny * (x - 1));
+    if (x <= g.nx - 2) r += (-c.ax) * u(bxo + y + g.ny * x);
+    // Dy'
+    const i64 byo = g.offBy + g.byLayer * tl;
+    if (y >= 1) r += c.ay * u(byo + (y - 1) + (g.ny - 1) * x);
+    if (y <= g.ny - 2) r += (-c.ay) * u(byo + y + (g.ny - 1) * x);
+    rhs[node] = r + cvec[node];
+}
+
+int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *alpha, const double *cvec,
+               const double *weight, const double *u0_prev, double *rhs, hipStream_t st) {
+    if (g.Nphi <= 0) return 0;
+    if (weight)
+        hipLaunchKernelGGL(k_rhs<true>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, q, alpha, cvec, weight,
+                           u0_prev, rhs);
+    else
+        hipLaunchKernelGGL(k_rhs<false>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, q, alpha, cvec,
+                           weight, u0_prev, rhs);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_u0_tail(Grid g, const double *__restrict__ q,
+                                                             const double *__restrict__ alpha,
+                                                             const double *__restrict__ weight,
+                                                             double *__restrict__ out) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    if (y >= g.ny || x >= g.nx) return;
+    const i64 k = y + g.ny * (x + g.nx * (g.ncl - 1));
+    out[y + g.ny * x] = WEIGHTED ? weight[k] * q[k] - alpha[k] : q[k] - alpha[k];
+}
+
+int launch_u0_tail(const Grid &g, const double *q, const double *alpha, const double *weight, double *out,
+                   hipStream_t st) {
+    if (g.ncl <= 0) return 0;
+    if (weight)
+        hipLaunchKernelGGL(k_u0_tail<true>, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, q, alpha, weight, out);
+    else
+        hipLaunchKernelGGL(k_u0_tail<false>, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, q, alpha, weight, out);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// q-step and alpha update, one staggered entry per thread:
+//   tmp = (A phi)_k ; q2 = (F* B* (z + beta))_k
+//   q_k = (w_k (tmp + alpha_k) + q2) * diagQInv_k          (solver_socp_inPALM.m:204-206; w: :212)
+//   alpha_k += tau (tmp - w_k q_k)                           (:211,214; w: :217)
+// diagQInv = 1 ./ oper_q  (socp/dot2d/utils/oper_q.m:13-26, wdot2d/utils/oper_q.m:15-28)
+// ---------------------------------------------------------------------------------------
+struct WSum {
+    const double *z, *b;
+    i64 Nz;
+    __device__ __forceinline__ double operator()(int j, i64 cell) const { return z[j * Nz + cell] + b[j * Nz + cell]; }
+};
+
+template <bool WEIGHTED>
+__device__ __forceinline__ void q_update(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
+                                         const double *__restrict__ weight, double *__restrict__ q,
+                                         double *__restrict__ alpha) {
+    const double a = alpha[k];
+    double qn, r;
+    if (WEIGHTED) {
+        const double w = weight[k];
+        const double di = 1.0 / (diag_c + w * w);
+        qn = (w * (tmp + a) + q2) * di;
+        r = tmp - w * qn;
+    } else {
+        qn = (tmp + a + q2) * dinv;
+        r = tmp - qn;
+    }
+    q[k] = qn;
+    alpha[k] = a + c.tau * r;
+}
+
+template <bool WEIGHTED, int SEG>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep(Grid g, LoopCoef c, const double *__restrict__ phi,
+                                                           const double *__restrict__ z,
+                                                           const double *__restrict__ beta,
+                                                           const double *__restrict__ weight,
+                                                           const double *__restrict__ tail_bx,
+                                                           const double *__restrict__ tail_by,
+                                                           double *__restrict__ q, double *__restrict__ alpha) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    const i64 tl = blockIdx.z;
+    WSum W{z, beta, g.Nz};
+    const i64 node = y + g.ny * (x + g.nx * tl);
+    if (SEG == 0) {
+        if (y >= g.ny || x >= g.nx) return;
+        double tmp = (-c.at) * phi[node];
+        tmp += c.at * phi[node + g.plane];
+        const double q2 = c.s * (W(9, node) - W(0, node));
+        q_update<WEIGHTED>(c, tmp, q2, c.c1, c.dinv1, node, weight, q, alpha);
+    } else {
+        const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
+        const double dc = tbnd ? c.c2 : c.c1;
+        const double di = tbnd ? c.dinv2 : c.dinv1;
+        if (SEG == 1) {
+            if (y >= g.ny || x >= g.nx - 1) return;
+            double tmp = (-c.ax) * phi[node];
+            tmp += c.ax * phi[node + g.ny];
+            const double q2 = c.sf * gather_bx(g, W, y, x, tl, tail_bx);
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, g.offBx + g.bxLayer * tl + y + g.ny * x, weight, q, alpha);
+        } else {
+            if (y >= g.ny - 1 || x >= g.nx) return;
+            double tmp = (-c.ay) * phi[node];
+            tmp += c.ay * phi[node + 1];
+            const double q2 = c.sf * gather_by(g, W, y, x, tl, tail_by);
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, g.offBy + g.byLayer * tl + y + (g.ny - 1) * x, weight, q, alpha);
+        }
+    }
+}
+
+template <bool WEIGHTED>
+static int launch_qstep_t(const Grid &g, const LoopCoef &c, const double *phi, const double *z, const double *beta,
+                          const double *weight, const double *tail_bx, const double *tail_by, double *q,
+                          double *alpha, hipStream_t st) {
+    dim3 blk(TILE_Y, TILE_X);
+    if (g.Nz > 0)
+        hipLaunchKernelGGL((k_qstep<WEIGHTED, 0>), tile_grid(g, g.ncl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
+                           tail_by, q, alpha);
+    if (g.bxLayer > 0)
+        hipLaunchKernelGGL((k_qstep<WEIGHTED, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
+                           tail_by, q, alpha);
+    if (g.byLayer > 0)
+        hipLaunchKernelGGL((k_qstep<WEIGHTED, 2>), tile_grid(g, g.ntl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
+                           tail_by, q, alpha);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_qstep(const Grid &g, const LoopCoef &c, const double *phi, const double *z, const double *beta,
+                 const double *weight, const double *tail_bx, const double *tail_by, double *q, double *alpha,
+                 hipStream_t st) {
+    return weight ? launch_qstep_t<true>(g, c, phi, z, beta, weight, tail_bx, tail_by, q, alpha, st)
+                  : launch_qstep_t<false>(g, c, phi, z, beta, weight, tail_bx, tail_by, q, alpha, st);
+}
+
+// x = x * mul / div  (left to right, like `alpha * dScale2 / cScale2^2`, solver_socp_inPALM.m:170-178,312-314)
+__global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, i64 n, double mul, double div, int use_mul) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        double v = x[i];
+        if (use_mul) v = v * mul;
+        x[i] = v / div;
+    }
+}
+
+int launch_scale(double *x, i64 n, double mul, double div, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scale, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, x, n, mul, div,
+                       (int)(mul != 1.0));
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dotsocp

@@ -1,0 +1,201 @@
+/*
+ * dotsocp.h -- C ABI of libdotsocp, the MI355X (gfx950) implementation of the
+ * inPALM/ADMM SOCP iteration loop of chlhnu/DOT-SOCP.
+ *
+ * Two drop-in boundaries:
+ *
+ *   B2  operator level -- the five MEX operators the reference ships as binaries.
+ *       Host pointers in MATLAB column-major layout; like the MEX files, the FIRST
+ *       argument is overwritten in place.  A MEX gateway binds them one-to-one
+ *       (dot-socp_amd/mex/).
+ *
+ *   B1  solver level -- [runHist, sigma] = solver_socp_inPALM(var, opts, model)
+ *       (socp/dot2d/algorithms/solver_socp_inPALM.m:1, the dot1d twin, and
+ *       socp/wdot2d/algorithms/solver_wsocp_inPALM.m:1).  The device owns the whole
+ *       loop state between create() and destroy(); the caller uploads the fields of
+ *       VarHandle / ModelHandle once, runs, and downloads the iterates.
+ *
+ * All functions return 0 on success and a negative DOTSOCP_E* code otherwise;
+ * dotsocp_last_error() returns a thread-local description.  No exceptions cross the
+ * ABI.  There is NO CPU fallback: without a HIP device every compute entry point
+ * fails with DOTSOCP_ENODEVICE.
+ *
+ * Layout conventions (identical to the reference): grid ny x nx x nt, y fastest, then
+ * x, then t;  Nphi = ny*nx*nt, Nz = ny*nx*(nt-1), Nbx = ny*(nx-1)*nt,
+ * Nby = (ny-1)*nx*nt, Nq = Nz+Nbx+Nby;  q = [q0; bx; by];  z, beta = Nz x 10
+ * column-major (1-D problems: grid nx x nt, q = [q0; bx], z = Nz x 6).
+ */
+#ifndef DOTSOCP_H
+#define DOTSOCP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef long long dotsocp_i64;
+
+enum {
+    DOTSOCP_OK = 0,
+    DOTSOCP_EINVAL = -1,     /* bad argument (sizes, NULL, unknown field)            */
+    DOTSOCP_ENODEVICE = -2,  /* no HIP device / HIP runtime error at initialisation  */
+    DOTSOCP_EHIP = -3,       /* a HIP call or kernel failed                          */
+    DOTSOCP_ESTATE = -4,     /* call sequence violated (e.g. run() before begin())   */
+    DOTSOCP_ECOMM = -5       /* RCCL / communicator failure                          */
+};
+
+const char *dotsocp_last_error(void);
+const char *dotsocp_version(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int dotsocp_device_count(void);
+
+/* ===================================================================================
+ * B2 -- operator level, HOST pointers (replaces the reference MEX binaries)
+ * =================================================================================== */
+
+/* mexProjSoc(out, in)  -- socp/{dot1d,dot2d,wdot2d}/utils/mexProjSoc.mexa64;
+ * call sites socp/dot2d/algorithms/solver_socp_inPALM.m:199,240.
+ * Row-wise projection of the M x K column-major matrix `in` onto {x1 >= ||x_2..K||}. */
+int dotsocp_proj_soc(double *out, const double *in, dotsocp_i64 M, dotsocp_i64 K);
+
+/* mexBFd(z, q, nt, nx, ny, scale, dF)  -- socp/dot2d/utils/mexBFd.mexa64;
+ * call sites solver_socp_inPALM.m:133,187,212,242.   z <- B F q + d  (Nz x 10).
+ * Slots whose edge lies outside the domain are not written (keep the caller's value). */
+int dotsocp_bfd(double *z, const double *q, dotsocp_i64 nt, dotsocp_i64 nx, dotsocp_i64 ny,
+                double scale, double dF);
+
+/* mexBFdConj(q, z, nt, nx, ny, scale)  -- socp/dot2d/utils/mexBFdConj.mexa64;
+ * call sites solver_socp_inPALM.m:205,225; socp/dot2d/utils/jump_nextLevel.m:16.
+ * q <- F* B* z  (Nq). */
+int dotsocp_bfd_conj(double *q, const double *z, dotsocp_i64 nt, dotsocp_i64 nx, dotsocp_i64 ny,
+                     double scale);
+
+/* mexBFd1d(z, q, nt, nx, scale, dF)  -- socp/dot1d/utils/mexBFd1d.mexa64;
+ * call sites socp/dot1d/algorithms/solver_socp_inPALM.m:132,186,211,241.  z is Nz x 6. */
+int dotsocp_bfd1d(double *z, const double *q, dotsocp_i64 nt, dotsocp_i64 nx, double scale, double dF);
+
+/* mexBFdConj1d(q, z, nt, nx, scale)  -- socp/dot1d/utils/mexBFdConj1d.mexa64;
+ * call sites socp/dot1d/algorithms/solver_socp_inPALM.m:204,224. */
+int dotsocp_bfd_conj1d(double *q, const double *z, dotsocp_i64 nt, dotsocp_i64 nx, double scale);
+
+/* res = oper_poisson3dim(kernelScale * initialize_FFTkernel(nt,nx,ny), rhs)
+ * -- socp/dot2d/utils/oper_poisson3dim.m:4, initialize_FFTkernel.m:6-15,
+ *    mirt_dctn.m / mirt_idctn.m (orthonormal DCT-II / DCT-III along every axis);
+ *    call site solver_socp_inPALM.m:96,194.   For a 1-D problem pass ny = nx1d, nx = 1
+ *    (socp/dot1d/utils/oper_poisson.m:4).  rhs and res hold ny*nx*nt doubles. */
+int dotsocp_oper_poisson(double *res, const double *rhs, dotsocp_i64 ny, dotsocp_i64 nx,
+                         dotsocp_i64 nt, double kernelScale);
+
+/* a <- dctn(a) (inverse = 0) or idctn(a) (inverse = 1) of an ny x nx x nt array
+ * -- socp/dot2d/utils/mirt_dctn.m:64-141, mirt_idctn.m:59-128. */
+int dotsocp_dctn(double *a, dotsocp_i64 ny, dotsocp_i64 nx, dotsocp_i64 nt, int inverse);
+
+/* Same operators on DEVICE pointers (no PCIe traffic), enqueued on `stream`
+ * (a hipStream_t, NULL = default stream).  Used by the parity tests and by bench.py. */
+int dotsocp_proj_soc_dev(double *d_out, const double *d_in, dotsocp_i64 M, dotsocp_i64 K, void *stream);
+int dotsocp_bfd_dev(double *d_z, const double *d_q, dotsocp_i64 nt, dotsocp_i64 nx, dotsocp_i64 ny,
+                    double scale, double dF, void *stream);
+int dotsocp_bfd_conj_dev(double *d_q, const double *d_z, dotsocp_i64 nt, dotsocp_i64 nx, dotsocp_i64 ny,
+                         double scale, void *stream);
+
+/* ===================================================================================
+ * B1 -- solver level (replaces solver_socp_inPALM.m / solver_wsocp_inPALM.m)
+ * =================================================================================== */
+
+typedef struct dotsocp_ctx dotsocp_ctx;
+
+/* Discrete model + scaling state on entry: the scalar fields of VarHandle / ModelHandle
+ * (socp/dot2d/utils/VarHandle.m:3-17, ModelHandle.m:3-16) after InitialScaling
+ * (socp/dot2d/solver_dotsocp2d.m:304-365). */
+typedef struct {
+    int dim;               /* 2: grid ny x nx x nt; 1: grid nx x nt (ny ignored)            */
+    int weighted;          /* 1: solver_wsocp_inPALM semantics, model.weight uploaded       */
+    dotsocp_i64 ny, nx, nt;
+    double D, E;           /* var.D, var.E                                                   */
+    double cScale, dScale; /* var.cScale, var.dScale                                         */
+    double normc, normd;   /* model.normc, model.normd                                       */
+} dotsocp_problem;
+
+/* opts struct read by the loop (solver_socp_inPALM.m:20-37,64-68) */
+typedef struct {
+    double tau;                 /* 1.9 inPALM, 1.0 ALG2 (solver_dotsocp2d.m:100-101,133-137) */
+    double sigma;               /* initial penalty                                          */
+    double tol;
+    dotsocp_i64 maxit;
+    int ifCheckStepByStep;
+    int checkPrimDualFeas;      /* -1 = reference default (true; weighted: false)           */
+    int scaling;                /* enables the in-loop rescale block (:64-77,138-190)        */
+    double time_limit;          /* seconds; <= 0 means the reference default 3600           */
+} dotsocp_opts;
+
+/* Field selectors for upload / download */
+enum {
+    DOTSOCP_F_PHI = 0,   /* Nphi                                  var.phi        */
+    DOTSOCP_F_Q = 1,     /* Nq                                    var.q          */
+    DOTSOCP_F_ALPHA = 2, /* Nq                                    var.alpha      */
+    DOTSOCP_F_Z = 3,     /* Nz x 10 (1-D: Nz x 6)                 var.z          */
+    DOTSOCP_F_BETA = 4,  /* Nz x 10 (1-D: Nz x 6)                 var.beta       */
+    DOTSOCP_F_C = 5,     /* Nphi                                  model.c        */
+    DOTSOCP_F_WEIGHT = 6 /* Nq (weighted only)                    model.weight   */
+};
+
+/* Loop outputs (solver_socp_inPALM.m:329-357) */
+typedef struct {
+    double sigma;          /* returned `sigma` = sigma / sigmaScale (:357)                  */
+    double sigma_internal; /* sigma used to un-scale alpha,beta on download (:335-336)      */
+    double cScale, dScale; /* var.cScale / var.dScale after in-loop rescales (:344-345)     */
+    double times[7];       /* Step_1_1_FFT, Step_1_2_ProjSOC, Step_2_Q_Step,
+                              Step_3_Multiplier, KKT, Total_Time, Iters (:339-341)          */
+    dotsocp_i64 iters;     /* iterations executed                                           */
+    dotsocp_i64 hist_len;  /* runHist.len                                                   */
+    int stopped;           /* 1 when the stop criterion (:287-290) fired                    */
+} dotsocp_result;
+
+/* `device` = HIP device ordinal.  `nslabs` >= 1 splits the time axis into that many
+ * slabs that live in this one process (the multi-GPU algorithm -- halo exchange and the
+ * slab<->pencil transposes of the Poisson solve -- executed with device-to-device
+ * copies); production multi-GPU runs use one process per GPU, nslabs = 1 and a
+ * communicator attached with dotsocp_attach_rccl(). */
+dotsocp_ctx *dotsocp_create(const dotsocp_problem *prob, int device, int nslabs);
+void dotsocp_destroy(dotsocp_ctx *ctx);
+
+/* One process per GPU: this process owns time slab `rank` of `world`.  `unique_id` is the
+ * 128-byte ncclUniqueId produced by dotsocp_rccl_unique_id() on rank 0 and broadcast by
+ * the host (torch.distributed / MPI / MATLAB parallel pool).  Must be called right after
+ * create() (before any upload).  With a communicator attached, upload/download take and
+ * return the LOCAL slab of each field (dotsocp_slab_range()). */
+int dotsocp_rccl_unique_id(unsigned char id[128]);
+int dotsocp_attach_rccl(dotsocp_ctx *ctx, const unsigned char id[128], int rank, int world);
+
+/* Time-slab partition used by the multi-GPU mode (pure host arithmetic, no device):
+ * nodes [*t0, *t1) of the nt time nodes belong to slab `rank`; its staggered cells are
+ * [*t0, min(*t1, nt-1)). */
+int dotsocp_slab_range(dotsocp_i64 nt, int world, int rank, dotsocp_i64 *t0, dotsocp_i64 *t1);
+
+int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host);
+int dotsocp_download(dotsocp_ctx *ctx, int field, double *host);
+
+/* solver_socp_inPALM.m:11-135 (setup), :136-325 (loop; `n_iters` < 0 = until maxit /
+ * stop), :329-357 (outputs).  run() may be called repeatedly; the trajectory is identical
+ * to a single call.  After finish(), download PHI/Q/Z/ALPHA/BETA gives var.* of :332-336
+ * (alpha and beta multiplied by sigma). */
+int dotsocp_begin(dotsocp_ctx *ctx, const dotsocp_opts *opts);
+int dotsocp_run(dotsocp_ctx *ctx, dotsocp_i64 n_iters, dotsocp_i64 *done);
+int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res);
+
+/* runHist.{kkt (len x 7, column-major), time, iter, pdGap} (:350-354); any pointer may be NULL */
+int dotsocp_get_history(dotsocp_ctx *ctx, double *kkt, double *time, double *iter, double *pdGap);
+
+/* Diagnostics for bench.py: average device time in ms of the named kernel family over
+ * the launches since begin() (HIP events on the launch stream), and its launch count.
+ * names: "cone_proj", "beta", "qstep", "rhs", "poisson", "kkt". Profiling must be enabled
+ * with dotsocp_set_profiling(ctx, 1) before begin(). */
+int dotsocp_set_profiling(dotsocp_ctx *ctx, int on);
+int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dotsocp_i64 *launches);
+
+/* Blocks until all work enqueued by this context has completed. */
+int dotsocp_synchronize(dotsocp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOTSOCP_H */

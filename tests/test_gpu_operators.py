@@ -1,0 +1,118 @@
+"""Operator-level parity (boundary B2): the HIP kernels behind mexProjSoc / mexBFd / mexBFdConj /
+mexBFd1d / mexBFdConj1d / oper_poisson3dim against the CPU oracle on identical seeded inputs.
+All calls go through the C ABI (ctypes -> lib/libdotsocp.so)."""
+import numpy as np
+import pytest
+import scipy.fft as sfft
+
+import dotsocp_amd as D
+from oracle import mexops as O
+from oracle.model import initialize_FFTkernel, oper_poisson
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(2024)
+
+
+def _sizes(nt, nx, ny):
+    Nz = ny * nx * (nt - 1)
+    return Nz, Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt
+
+
+@pytest.mark.parametrize("M,K", [(1, 10), (777, 10), (100000, 10), (513, 6), (64, 2), (300, 13)])
+def test_proj_soc_bit_exact(M, K):
+    x = np.asfortranarray(rng.standard_normal((M, K)) * rng.choice([0.1, 1, 30], size=(M, 1)))
+    ref = np.empty_like(x, order="F")
+    got = np.full_like(x, -7.0, order="F")
+    O.mexProjSoc(ref, x)
+    D.mexProjSoc(got, x)
+    # same operation order, no FMA contraction on either side: results are identical
+    assert np.array_equal(got, ref)
+
+
+def test_proj_soc_edge_rows():
+    """zero row -> NaN, n = 0 with x1 > 0 -> unchanged, x1 < 0 -> zero, boundary of the cone, +-inf"""
+    x = np.zeros((7, 10), order="F")
+    x[1, 0] = 3.0
+    x[2, 0] = -3.0
+    x[3, :2] = [1.0, 1.0]
+    x[4, :2] = [-1.0, 1.0]
+    x[5] = 1e-200
+    x[6] = 1e150
+    ref, got = np.empty_like(x, order="F"), np.empty_like(x, order="F")
+    O.mexProjSoc(ref, x)
+    D.mexProjSoc(got, x)
+    assert np.all(np.isnan(got[0])) and np.array_equal(got[1], x[1]) and np.all(got[2] == 0)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("nt,nx,ny", [(2, 1, 1), (2, 2, 2), (4, 6, 5), (3, 70, 130), (9, 17, 64), (5, 1, 100), (5, 100, 1)])
+def test_bfd_and_conj(nt, nx, ny):
+    Nz, Nq = _sizes(nt, nx, ny)
+    s, dF = 0.731, 1.37
+    q = rng.standard_normal(Nq)
+    z0 = np.asfortranarray(rng.standard_normal((Nz, 10)))        # sentinel values in unwritten slots
+    ref, got = z0.copy(order="F"), z0.copy(order="F")
+    O.mexBFd(ref, q, nt, nx, ny, s, dF)
+    D.mexBFd(got, q, nt, nx, ny, s, dF)
+    assert np.array_equal(got, ref)
+    w = np.asfortranarray(rng.standard_normal((Nz, 10)))
+    qr, qg = np.zeros(Nq), np.full(Nq, 5.0)
+    O.mexBFdConj(qr, w, nt, nx, ny, s)
+    D.mexBFdConj(qg, w, nt, nx, ny, s)
+    assert np.array_equal(qg, qr)
+    # adjoint identity on the device results themselves
+    z = np.zeros((Nz, 10), order="F")
+    D.mexBFd(z, q, nt, nx, ny, s, 0.0)
+    assert abs(np.vdot(z, w) - np.vdot(q, qg)) <= 1e-12 * (np.linalg.norm(z) * np.linalg.norm(w) + 1)
+
+
+def test_bfd_defaults():
+    nt, nx, ny = 3, 4, 5
+    Nz, Nq = _sizes(nt, nx, ny)
+    q = rng.standard_normal(Nq)
+    a, b = np.zeros((Nz, 10), order="F"), np.zeros((Nz, 10), order="F")
+    D.mexBFd(a, q, float(nt), float(nx), float(ny))              # doubles are truncated, scale = dF = 1
+    O.mexBFd(b, q, nt, nx, ny, 1.0, 1.0)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nt,nx", [(2, 2), (4, 9), (33, 129), (5, 300)])
+def test_bfd1d_and_conj1d(nt, nx):
+    Nz = nx * (nt - 1)
+    Nq = Nz + (nx - 1) * nt
+    s, dF = 1.21, 0.6
+    q = rng.standard_normal(Nq)
+    z0 = np.asfortranarray(rng.standard_normal((Nz, 6)))
+    ref, got = z0.copy(order="F"), z0.copy(order="F")
+    O.mexBFd1d(ref, q, nt, nx, s, dF)
+    D.mexBFd1d(got, q, nt, nx, s, dF)
+    assert np.array_equal(got, ref)
+    w = np.asfortranarray(rng.standard_normal((Nz, 6)))
+    qr, qg = np.zeros(Nq), np.zeros(Nq)
+    O.mexBFdConj1d(qr, w, nt, nx, s)
+    D.mexBFdConj1d(qg, w, nt, nx, s)
+    assert np.array_equal(qg, qr)
+
+
+@pytest.mark.parametrize("shape", [(8, 4, 2), (64, 32, 16), (256, 8, 4), (16, 256, 8), (4, 16, 128), (1024, 2, 2),
+                                   (5, 6, 7), (33, 17, 9), (129, 3, 2), (16, 1, 8), (129, 1, 33)])
+def test_dctn_matches_scipy(shape):
+    a = np.asfortranarray(rng.standard_normal(shape))
+    tol = 2e-13 * np.sqrt(np.prod(shape))
+    np.testing.assert_allclose(D.mirt_dctn(a), sfft.dctn(a, norm="ortho"), atol=tol)
+    np.testing.assert_allclose(D.mirt_idctn(a), sfft.idctn(a, norm="ortho"), atol=tol)
+    np.testing.assert_allclose(D.mirt_idctn(D.mirt_dctn(a)), a, atol=tol)
+
+
+@pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32)])
+def test_oper_poisson(ny, nx, nt):
+    Dsc = 0.37
+    rhs = np.asfortranarray(rng.standard_normal((ny, nx, nt)))
+    if nx == 1:
+        kernel = Dsc ** 2 * initialize_FFTkernel(nt, ny)          # 1-D problem: grid nx1d x nt
+        ref = oper_poisson(kernel, rhs.reshape((ny, nt), order="F")).ravel(order="F")
+    else:
+        kernel = Dsc ** 2 * initialize_FFTkernel(nt, nx, ny)
+        ref = oper_poisson(kernel, rhs).ravel(order="F")
+    got = D.oper_poisson3dim(Dsc ** 2, rhs)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())

@@ -1,0 +1,127 @@
+"""Solver-level parity (boundary B1): the device-resident inPALM loop against the CPU oracle on
+identical rho0/rho1 inputs -- fixed-length trajectories (every iterate compared) and free-running
+solves (same stop iteration, KKT history, mass conservation).  Tolerance: the loop is fp64 and
+differs from the oracle only in the summation order of the DCT and of the global norms, so
+trajectories agree to ~1e-12 relative after tens of iterations; the bar asserted here is 1e-9
+(SURVEY.md section 8d "parity gate")."""
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from oracle import driver as OD
+from oracle.examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, get_example_1d,
+                             get_example_2d, get_weight_by_barrier)
+from oracle.inpalm import InPALMState
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("phi", "q", "z", "alpha", "beta")
+
+
+def _gpu_level(rho0, rho1, nt, opts, method="inPALM", weight=None):
+    dim = 2 if np.ndim(rho0) == 2 else 1
+    var, model = D.initialize(rho0, rho1, nt)
+    if weight is not None:
+        model.weight = np.asarray(weight, dtype=np.float64)
+    o = OD.default_opts(opts, method, weight is not None)
+    D.InitialScaling(var, model, o["scaling"], None, dim=dim, weighted=weight is not None)
+    return var, model, o
+
+
+def _relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _compare_run(rho0, rho1, nt, opts, K, weight=None, method="inPALM", tol=1e-9):
+    opts = dict(opts, maxit=K)
+    ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, method, weight)
+    st = InPALMState(ovar, oo, omodel, weighted=weight is not None)
+    st.run()
+    o_hist, o_sigma = st.finish()
+    gvar, gmodel, go = _gpu_level(rho0, rho1, nt, opts, method, weight)
+    # host-side set-up must agree exactly (same formulas)
+    assert gvar.D == ovar.D and gvar.E == ovar.E
+    solve = D.solver_wsocp_inPALM if weight is not None else D.solver_socp_inPALM
+    g_hist, g_sigma = solve(gvar, go, gmodel)
+    assert g_hist["len"] == o_hist["len"]
+    np.testing.assert_array_equal(g_hist["iter"], o_hist["iter"])
+    assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
+    np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-6, atol=1e-15)
+    np.testing.assert_allclose(g_hist["pdGap"], o_hist["pdGap"], rtol=1e-6, atol=1e-14)
+    errs = {f: _relerr(getattr(gvar, f), getattr(ovar, f)) for f in FIELDS}
+    assert max(errs.values()) <= tol, errs
+    assert abs(gvar.cScale - ovar.cScale) <= 1e-12 * ovar.cScale
+    assert abs(gvar.dScale - ovar.dScale) <= 1e-12 * ovar.dScale
+    return errs
+
+
+@pytest.mark.parametrize("n,nt,K", [(16, 8, 1), (16, 8, 5), (32, 16, 60), (64, 32, 30), (33, 17, 25)])
+def test_trajectory_dot2d(n, nt, K):
+    rho0, rho1 = get_example_2d("example1", n, n)
+    _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
+
+
+def test_trajectory_dot2d_rectangular_alg2():
+    rho0, rho1 = get_example_2d("example1", 24, 40)     # generator returns (nx, ny) arrays: ny = 24, nx = 40
+    _compare_run(rho0, rho1, 12, dict(tol=0.0), 20, method="ALG2")
+
+
+def test_trajectory_no_scaling_checkstep():
+    rho0, rho1 = get_example_2d("example1", 16, 16)
+    _compare_run(rho0, rho1, 8, dict(tol=0.0, scaling=False, sigma=0.1, ifCheckStepByStep=True), 12)
+
+
+@pytest.mark.parametrize("nx,nt,K", [(64, 16, 40), (129, 33, 40), (128, 32, 80)])
+def test_trajectory_dot1d(nx, nt, K):
+    rho0, rho1 = get_example_1d("gaussian", nx)
+    _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
+
+
+@pytest.mark.parametrize("n,nt,K", [(32, 16, 40), (33, 9, 20)])
+def test_trajectory_wdot2d(n, nt, K):
+    rho0, rho1 = get_example_2d("example1", n, n)
+    barrier = gene_barrier_of_circle_pillar()
+    weight = get_weight_by_barrier(n, n, nt, barrier)
+    rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    assert (weight == 1e6).sum() > 0
+    _compare_run(rho0, rho1, nt, dict(tol=0.0), K, weight=weight, tol=1e-8)
+
+
+def test_free_running_solve_dot2d():
+    """Full solve to tolerance through the driver: same stop iteration as the oracle, KKT < tol,
+    per-layer mass conservation (solver_dotsocp2d.m:283-287)."""
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    ovar, omodel, o_hist, o_sigma = OD.solve_single_level(rho0, rho1, 16, dict(tol=1e-4))
+    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 16, 1, dict(tol=1e-4), "inPALM")
+    assert hist["iter"][-1] == o_hist["iter"][-1]
+    assert np.max(hist["kkt"][-1][[0, 2, 5, 6]]) < 1e-4
+    np.testing.assert_allclose(hist["kkt"][-1], o_hist["kkt"][-1], rtol=1e-6, atol=1e-14)
+    rho_o, Ex_o, Ey_o = OD.recover_RhoE(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-8)
+    assert D.check_massConservation(out["rho"], 1e-2)
+    assert timeML[0]["Iters"] == hist["iter"][-1]
+
+
+def test_free_running_solve_dot1d():
+    rho0, rho1 = get_example_1d("gaussian", 129)
+    ovar, omodel, o_hist, o_sigma = OD.solve_single_level(rho0, rho1, 33, dict(tol=1e-4))
+    out, timeML, histML, hist = D.solver_dotsocp1d(rho0, rho1, 33, 1, dict(tol=1e-4), "inPALM")
+    assert hist["iter"][-1] == o_hist["iter"][-1] == 364        # SURVEY.md 8c(iii) known answer
+    assert D.check_massConservation(out["rho"], 1e-2)
+    rho_o, Ex_o = OD.recover_RhoE_1d(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-7)
+
+
+def test_run_in_pieces_is_identical():
+    """dotsocp_run(n) called repeatedly gives the same trajectory as one call (bench warm-up + timed region)."""
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    res = []
+    for pieces in ((40,), (7, 13, 20)):
+        var, model, o = _gpu_level(rho0, rho1, 16, dict(tol=0.0, maxit=40))
+        ctx = D.InPALMContext(var, o, model)
+        for k in pieces:
+            assert ctx.run(k) == k
+        hist, sigma = ctx.finish()
+        ctx.close()
+        res.append((var.phi.copy(), var.beta.copy(), sigma, hist["kkt"].copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and np.array_equal(res[0][3], res[1][3])
