@@ -45,7 +45,9 @@ def _compare_run(rho0, rho1, nt, opts, K, weight=None, method="inPALM", tol=1e-9
     assert g_hist["len"] == o_hist["len"]
     np.testing.assert_array_equal(g_hist["iter"], o_hist["iter"])
     assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
-    np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-6, atol=1e-15)
+    # column 5 (||F*B*beta + D_w alpha||) is an exact-cancellation residual: pure rounding noise
+    # (1e-16 unweighted, 1e-11 with 1e6 barrier weights), hence the absolute floor
+    np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(g_hist["pdGap"], o_hist["pdGap"], rtol=1e-6, atol=1e-14)
     errs = {f: _relerr(getattr(gvar, f), getattr(ovar, f)) for f in FIELDS}
     assert max(errs.values()) <= tol, errs
