@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM (inPALM) iterations per second of the device-resident loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one inPALM iteration (phi-step, cone projection, q-step, multipliers, plus the
+KKT block at the reference's own cadence, solver_socp_inPALM.m:361-379) on the synthetic
+Gaussian-to-Gaussian problem of BASELINE.json (Example 5.1, examples/dot2d/gene_example1.m),
+levelN = 1, method "inPALM" (tau = 1.9, sigma0 = 1, scaling on), tol = 0 so that every run executes
+exactly W + K iterations.  Inputs are resident in HBM before the timed region starts.
+
+N = 1: dot2d 1024 x 1024 x 128 (BASELINE.json configs[2]).  N > 1: the same grid split into N time
+slabs, one process per GPU (strong scaling).  Rank 0 prints ONE JSON line; besides the contract
+fields it carries `roofline` (cone-projection kernel, HIP-event timing on the launch stream) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NY", "NX", "NT"),
+                    help="override the grid (default 1024 1024 128)")
+    ap.add_argument("--workload", choices=["dot2d", "wdot2d", "dot1d"], default="dot2d")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def build_problem(D, workload, ny, nx, nt):
+    """Synthetic inputs + one level of the driver (initialize + InitialScaling), cold start."""
+    weight = None
+    if workload == "dot1d":
+        rho0, rho1 = D.get_example_1d("gaussian", ny)
+        dim = 1
+    else:
+        # like demo_dot2d.m:40,63 the generator's output goes to the solver as is; its first
+        # dimension becomes the solver's ny (socp/dot2d/utils/initialize.m:8-9)
+        rho0, rho1 = D.get_example_2d("example1", ny, nx)
+        dim = 2
+        if workload == "wdot2d":
+            barrier = D.gene_barrier_of_circle_pillar()
+            weight = D.get_weight_by_barrier(nx, ny, nt, barrier)
+            rho0, rho1, _ = D.ensure_barrier_validity(rho0, rho1, barrier)
+    var, model = D.initialize(rho0, rho1, nt, lazy_zeros=True)
+    if weight is not None:
+        model.weight = weight
+    D.InitialScaling(var, model, True, None, dim=dim, weighted=weight is not None)
+    return var, model, rho0, rho1, weight
+
+
+def cpu_baseline(workload, ny, nx, nt, budget_s):
+    """The CPU oracle (numpy + C restatement of the reference dataflow: sparse A/A', FFT-based DCT,
+    single-threaded MEX-equivalent loops, same temporaries) timed on this box's host cores on a
+    bounded sample: the same spatial grid with a short time axis, a few iterations; throughput is
+    scaled to the full grid by the node-count ratio (every step of the loop is O(N))."""
+    from oracle import driver as OD
+    from oracle import examples as OE
+    from oracle.inpalm import InPALMState
+    nts = min(nt, 9)
+    # keep the sample below ~10 M nodes so that set-up (sparse kron) stays within seconds
+    while ny * nx * nts > 4_500_000 and nts > 3:
+        nts -= 1
+    weight = None
+    if workload == "dot1d":
+        rho0, rho1 = OE.get_example_1d("gaussian", ny)
+        nts = nt
+    else:
+        rho0, rho1 = OE.get_example_2d("example1", ny, nx)
+        if workload == "wdot2d":
+            barrier = OE.gene_barrier_of_circle_pillar()
+            weight = OE.get_weight_by_barrier(nx, ny, nts, barrier)
+            rho0, rho1, _ = OE.ensure_barrier_validity(rho0, rho1, barrier)
+    var, model, o = OD.make_level(rho0, rho1, nts, dict(tol=0.0, maxit=10 ** 6), "inPALM", weight)
+    st = InPALMState(var, o, model, weighted=weight is not None)
+    st.run(1)                                   # untimed first iteration (page faults, FFT plans)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 200):
+        st.run(1)
+        n += 1
+    dt = time.perf_counter() - t0
+    nodes_s = ny * (nx if workload != "dot1d" else 1) * nts
+    nodes_f = ny * (nx if workload != "dot1d" else 1) * nt
+    its_sample = n / dt
+    return {
+        "value": its_sample * nodes_s / nodes_f,
+        "unit": "iterations/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": (f"oracle (restated reference, no MATLAB available), {n} iterations on "
+                   f"{ny}x{nx}x{nts} = {its_sample:.4g} it/s, scaled by the node ratio "
+                   f"{nodes_s}/{nodes_f} to the {ny}x{nx}x{nt} grid; FFTs use all host threads, "
+                   f"the MEX-equivalent loops and numpy passes are single-threaded like the reference"),
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    import torch
+    import dotsocp_amd as D
+    if args.grid:
+        ny, nx, nt = args.grid
+    elif args.workload == "dot1d":
+        ny, nx, nt = 128, 1, 32
+    elif args.workload == "wdot2d":
+        ny, nx, nt = 512, 512, 128
+    else:
+        ny, nx, nt = 1024, 1024, 128
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        raise SystemExit("time-slab multi-GPU mode is not available in this build")
+    if D.capi.lib().dotsocp_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libdotsocp has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    var, model, rho0, rho1, weight = build_problem(D, args.workload, ny, nx, nt)
+    opts = dict(tau=1.9, sigma=1.0, tol=0.0, maxit=args.warmup + args.steps, scaling=True,
+                ifCheckStepByStep=False, time_limit=1e9)
+    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False)
+    done = ctx.run(args.warmup)
+    assert done == args.warmup
+    D.capi.check(D.capi.lib().dotsocp_set_profiling(ctx._ctx, 1))
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = ctx.run(args.steps)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert done == args.steps
+    hist, sigma = ctx.finish(download=False)
+    times = {k: ctx.kernel_time(k) for k in ("rhs", "poisson", "cone_proj", "qstep", "beta", "kkt")}
+    ctx.close()
+
+    Nz = ny * nx * (nt - 1)
+    Nq = Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt
+    proj_ms, proj_n = times["cone_proj"]
+    alg_bytes = 8.0 * (20 * Nz + Nq)          # beta in + q in + z out
+    achieved = alg_bytes / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "cone_proj_traffic.json")
+    if os.path.exists(tf):
+        try:
+            rec = json.load(open(tf))
+            if rec.get("grid") == [ny, nx, nt]:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "ADMM iters/sec on NxNxT dot2d staggered grid",
+        "value": args.steps / dt,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload} {ny}x{nx}x{nt} Gaussian-to-Gaussian (Example 5.1), inPALM tau=1.9, levelN=1",
+                   "grid": [ny, nx, nt], "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
+                   "parallelism": "1 GPU" if world == 1 else f"{world} time slabs"},
+        "roofline": {"bound": "hbm", "kernel": "k_cone_march<0> (cone projection)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_ms": proj_ms, "launches": proj_n},
+        "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

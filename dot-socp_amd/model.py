@@ -24,7 +24,7 @@ def normL2(x, h):
     return np.sqrt(h) * np.linalg.norm(np.ravel(x))
 
 
-def initialize(rho0, rho1, nt):
+def initialize(rho0, rho1, nt, lazy_zeros=False):
     """[var, model] = initialize(rho0, rho1, nt)
     socp/dot2d/utils/initialize.m:1-65 (rho0: ny x nx) / socp/dot1d/utils/initialize.m:1-58."""
     rho0 = np.asarray(rho0, dtype=np.float64)
@@ -59,10 +59,15 @@ def initialize(rho0, rho1, nt):
         model.c[n - nx:] = rho1.ravel() / ht
         var.phi = np.tile(0.5 * (np.arange(nx) * hx) ** 2, nt)
         K = 6
-    var.z = np.zeros((bx, K), order="F")
-    var.beta = np.zeros((bx, K), order="F")
-    var.q = np.zeros(nq)
-    var.alpha = np.zeros(nq)
+    if lazy_zeros:
+        # the all-zero start (initialize.m:52-59) is the device default: nothing to allocate or upload
+        var.z = var.beta = var.q = var.alpha = None
+        var.zshape, var.nq = (bx, K), nq
+    else:
+        var.z = np.zeros((bx, K), order="F")
+        var.beta = np.zeros((bx, K), order="F")
+        var.q = np.zeros(nq)
+        var.alpha = np.zeros(nq)
     model.grad = None        # matrix-free (see module docstring)
     return var, model
 
@@ -95,10 +100,11 @@ def InitialScaling(var, model, scalingYes, lastLevelKKT=None, dim=2, weighted=Fa
         model.normd = norm_d * E / dScale
         model.c = (1.0 / cScale) * model.c
         var.phi = (1.0 / dScale) * var.phi
-        var.q = (D / dScale) * var.q
-        var.z = (E / dScale) * var.z
-        var.alpha = (1.0 / cScale / D) * var.alpha
-        var.beta = (1.0 / cScale / E) * var.beta
+        if var.q is not None:
+            var.q = (D / dScale) * var.q
+            var.z = (E / dScale) * var.z
+            var.alpha = (1.0 / cScale / D) * var.alpha
+            var.beta = (1.0 / cScale / E) * var.beta
     else:
         cScale = dScale = D = E = 1.0
         model.normc = normL2(model.c, h)

@@ -50,11 +50,12 @@ class InPALMContext:
         self._ctx = L.dotsocp_create(ctypes.byref(p), int(device), int(nslabs))
         if not self._ctx:
             raise capi.DotsocpError(-1, L.dotsocp_last_error().decode())
-        self._shapes = {capi.F_Z: var.z.shape, capi.F_BETA: var.beta.shape}
         try:
+            # a field left as None keeps the device default (zeros), e.g. z, beta, q, alpha of a cold start
             for f, a in ((capi.F_PHI, var.phi), (capi.F_Q, var.q), (capi.F_ALPHA, var.alpha),
                          (capi.F_Z, var.z), (capi.F_BETA, var.beta), (capi.F_C, model.c)):
-                self.upload(f, a)
+                if a is not None:
+                    self.upload(f, a)
             if weighted:
                 self.upload(capi.F_WEIGHT, model.weight)
             if profiling:
@@ -95,18 +96,19 @@ class InPALMContext:
         capi.check(capi.lib().dotsocp_kernel_time(self._ctx, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
-    def finish(self):
+    def finish(self, download=True):
         """solver_socp_inPALM.m:329-357: write iterates and scaling factors back into `var`."""
         L = capi.lib()
         res = capi.Result()
         capi.check(L.dotsocp_finish(self._ctx, ctypes.byref(res)))
         var = self.var
         var.name = 'Inexact Proximal ALM'
-        var.phi = self.download(capi.F_PHI, var.phi)
-        var.q = self.download(capi.F_Q, var.q)
-        var.z = self.download(capi.F_Z, var.z)
-        var.alpha = self.download(capi.F_ALPHA, var.alpha)       # = sigma * alpha
-        var.beta = self.download(capi.F_BETA, var.beta)          # = sigma * beta
+        if download:
+            var.phi = self.download(capi.F_PHI, var.phi)
+            var.q = self.download(capi.F_Q, var.q)
+            var.z = self.download(capi.F_Z, var.z)
+            var.alpha = self.download(capi.F_ALPHA, var.alpha)       # = sigma * alpha
+            var.beta = self.download(capi.F_BETA, var.beta)          # = sigma * beta
         var.time = dict(zip(TIME_NAMES, list(res.times)))
         var.cScale, var.dScale = res.cScale, res.dScale
         n = int(res.hist_len)
