@@ -296,7 +296,8 @@ int dotsocp_set_profiling(dotsocp_ctx *ctx, int on) {
 int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dotsocp_i64 *launches) {
     CTX_OR_FAIL();
     DS_ARG(name != nullptr, "name is NULL");
-    static const char *names[PH_COUNT] = {"rhs", "poisson", "cone_proj", "qstep", "beta", "kkt"};
+    static const char *names[PH_COUNT] = {"rhs", "poisson", "cone_proj", "qstep", "beta", "kkt",
+                                          "cone_fused_a", "cone_fused_b", "materialise"};
     for (int i = 0; i < PH_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) {
             const i64 n = ctx->s.phase_launches[i];

@@ -1,0 +1,169 @@
+// The fused cone kernel of the inPALM loop: deferred multiplier update + cone projection +
+// adjoint gather in ONE pass over beta ("minimal fused dataflow"):
+//
+//   MODE_B (steady state), per cell, with q_old = q^{k-1}, q = q^k, beta_in = beta^{k-1}:
+//     z^k      = Pi_Q(BF q_old + d - beta_in)          recomputed, z is never stored        (:199 of it. k-1)
+//     beta^k   = beta_in + tau (z^k - (BF q + d))      multiplier step of iteration k-1     (:212-215)
+//     z^{k+1}  = Pi_Q(BF q + d - beta^k)               z-step of iteration k                (:199)
+//     q2       = F* B* (z^{k+1} + beta^k)              adjoint gather for the q-step        (:205)
+//   traffic: beta in + beta out + q_old + q + q2 = 8 (20 Nz + 3 Nq) bytes.
+//   MODE_A: same without the deferred update (beta already current): 8 (10 Nz + 2 Nq) bytes.
+//   MODE_M: materialise -- beta update + write z (needed by the KKT block / rescale / outputs).
+//   (line numbers: socp/dot2d/algorithms/solver_socp_inPALM.m)
+//
+// Mapping: a workgroup owns a 64 (y) x XB (x) tile of cell columns and MARCHES through a chunk
+// of time cells; one wavefront = 64 consecutive y of one x column, so every plane access is a
+// coalesced 512-byte segment.  The t+1 edge layer of q is carried in registers (each q entry is
+// fetched once per chunk), the cell's own "t+1" cone entries are carried to the next step in
+// registers, x-neighbour cone entries are exchanged through LDS (double-buffered, one barrier
+// per step) and y-neighbour entries through cross-lane shuffles.  Edges on a tile boundary get
+// a partial sum in q2 plus the neighbour tile's partial in a small side buffer (sx / sy); the
+// q-step adds the two.  Chunks after the first recompute the cell in front of them (reads only:
+// beta is ping-ponged, so no other workgroup's writes are observed).
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace dotsocp {
+
+template <int MODE, int XB>
+__global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, FusedArgs a) {
+    __shared__ double2 xch[2][XB][64];
+    const int lane = threadIdx.x, xl = threadIdx.y;
+    const i64 y = (i64)blockIdx.x * 64 + lane;
+    const i64 x = (i64)blockIdx.y * XB + xl;
+    const bool inb = (y < g.ny) && (x < g.nx);
+    const i64 yc = inb ? y : 0, xc = inb ? x : 0;      // clamped coordinates keep out-of-tile lanes harmless
+    const i64 t0 = (i64)blockIdx.z * a.TC;
+    const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
+    const bool lastChunk = (t1 == g.ncl);
+    const i64 tstart = (MODE != 2 && t0 > 0) ? t0 - 1 : t0;
+    const i64 nxblk = gridDim.y, nyblk = gridDim.x;
+
+    EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo;
+    if (MODE != 0) curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
+    double p3 = 0.0, p4 = 0.0, p7 = 0.0, p8 = 0.0;     // "t+1" cone entries of the previous cell
+    int par = 0;
+    // one extra virtual step (tl == ncl, no cell) on the last chunk emits the final edge layer
+    const i64 tstop = (MODE != 2 && lastChunk) ? t1 + 1 : t1;
+    for (i64 tl = tstart; tl < tstop; ++tl) {
+        const bool hasCell = tl < g.ncl;
+        const bool own = tl >= t0;                      // false only for the recomputed cell in front of the chunk
+        double w[10];
+        if (hasCell) {
+            const i64 i = yc + g.ny * (xc + g.nx * tl);
+            const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
+            double b[10], v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+            build_z2(v, a.q[i], cur, nxt, c.s, c.dF);
+            if (MODE != 0) {
+                const EdgeQuad nxto = load_edges(g, a.q_old, yc, xc, tl + 1, c.sf);
+                double zo[10];
+                build_z2(zo, a.q_old[i], curo, nxto, c.s, c.dF);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) zo[j] = zo[j] - b[j];
+                proj_row<10>(zo);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const double r = zo[j] - v[j];
+                    b[j] = b[j] + c.tau * r;
+                }
+                if (own && inb) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
+                    if (MODE == 2) {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zo[j];
+                    }
+                }
+                curo = nxto;
+            }
+            cur = nxt;
+            if (MODE != 2) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = v[j] - b[j];
+                proj_row<10>(v);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) w[j] = v[j] + b[j];
+                if (own && inb) a.q2[i] = c.s * (w[9] - w[0]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[j] = 0.0;
+        }
+        if (MODE != 2) {
+            // ---- adjoint gather for edge layer tl: ((w1(x+1) + w2(x)) + w3'(x+1)) + w4'(x), ' = previous cell
+            xch[par][xl][lane] = make_double2(w[1], p3);
+            __syncthreads();
+            if (own && inb) {
+                if (x < g.nx - 1) {
+                    const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+                    if (xl < XB - 1) {
+                        const double2 r = xch[par][xl + 1][lane];
+                        double acc = r.x + w[2];
+                        acc += r.y;
+                        acc += p4;
+                        a.q2[e] = c.sf * acc;
+                    } else {
+                        a.q2[e] = w[2] + p4;                        // partial; the right tile adds its part via sx
+                    }
+                }
+                if (xl == 0 && x > 0) a.sx[(tl * nxblk + blockIdx.y) * g.ny + y] = w[1] + p3;
+            }
+            const double u5 = __shfl_down(w[5], 1, 64), u7 = __shfl_down(p7, 1, 64);
+            if (own && inb) {
+                if (y < g.ny - 1) {
+                    const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+                    if (lane < 63) {
+                        double acc = u5 + w[6];
+                        acc += u7;
+                        acc += p8;
+                        a.q2[e] = c.sf * acc;
+                    } else {
+                        a.q2[e] = w[6] + p8;                        // partial; the upper tile adds its part via sy
+                    }
+                }
+                if (lane == 0 && y > 0) a.sy[(tl * g.nx + x) * nyblk + blockIdx.x] = w[5] + p7;
+            }
+            p3 = w[3]; p4 = w[4]; p7 = w[7]; p8 = w[8];
+            par ^= 1;
+        }
+    }
+}
+
+int fused_geometry(const Grid &g, FusedGeom &fg) {
+    fg.XB = 4;
+    fg.nyblk = (g.ny + 63) / 64;
+    fg.nxblk = (g.nx + fg.XB - 1) / fg.XB;
+    const i64 tiles = fg.nyblk * fg.nxblk;
+    // enough workgroups to fill 256 CUs several times over; each extra chunk costs one recomputed cell
+    i64 chunks = (2048 + tiles - 1) / tiles;
+    if (chunks < 1) chunks = 1;
+    i64 TC = (g.ncl + chunks - 1) / chunks;
+    if (TC < 8) TC = 8;
+    if (TC > g.ncl) TC = g.ncl;
+    if (TC < 1) TC = 1;
+    fg.TC = TC;
+    fg.chunks = (g.ncl + TC - 1) / TC;
+    fg.sx_len = (g.ncl + 1) * fg.nxblk * g.ny;
+    fg.sy_len = (g.ncl + 1) * g.nx * fg.nyblk;
+    return 0;
+}
+
+int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
+                      hipStream_t st) {
+    if (g.Nz <= 0) return 0;
+    a.TC = fg.TC;
+    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
+    dim3 blk(64, 4);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_cone_fused<0, 4>), grid, blk, 0, st, g, c, a); break;
+        case 1: hipLaunchKernelGGL((k_cone_fused<1, 4>), grid, blk, 0, st, g, c, a); break;
+        case 2: hipLaunchKernelGGL((k_cone_fused<2, 4>), grid, blk, 0, st, g, c, a); break;
+        default: set_error("bad fused mode"); return DOTSOCP_EINVAL;
+    }
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dotsocp

@@ -43,7 +43,37 @@ int launch_beta_update(const Grid &g, const LoopCoef &c, const double *q, const 
 int launch_gather_tail(const Grid &g, const double *z, const double *beta, double *tail_bx, double *tail_by,
                        hipStream_t st);
 
+// ---------------- fused.hip ----------------
+// Tile geometry of the fused cone kernel; the q-step needs it to find the edges whose adjoint
+// sum is split between q2 (own tile's part) and the side buffers sx / sy (neighbour tile's part).
+struct FusedGeom {
+    int XB;               // tile width in x (columns per workgroup); tile height in y is 64
+    i64 nyblk, nxblk;     // tiles in y / x
+    i64 TC, chunks;       // time cells per chunk, number of chunks
+    i64 sx_len, sy_len;   // side buffer lengths (doubles)
+};
+struct FusedArgs {
+    const double *q_old;    // q^{k-1} (modes 1, 2)
+    const double *q;        // q^k
+    const double *beta_in;
+    double *beta_out;       // modes 1, 2 (mode 1: must differ from beta_in when chunks > 1)
+    double *z_out;          // mode 2
+    double *q2;             // modes 0, 1: adjoint sums, q layout
+    double *sx, *sy;        // modes 0, 1: tile-boundary partial sums
+    i64 TC;
+};
+int fused_geometry(const Grid &g, FusedGeom &fg);
+// mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z
+int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
+                      hipStream_t st);
+
 // ---------------- stencil.hip ----------------
+// q-step + alpha update reading the precomputed adjoint sums q2 (+ side buffers) of the fused kernel;
+// writes q^{k+1} into q_out (q^k stays intact for the deferred beta update).
+int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi,
+                       const double *q2, const double *sx, const double *sy, const double *weight,
+                       const double *tail_bx, const double *tail_by, double *q_out, double *alpha,
+                       hipStream_t st);
 // rhs = A'(w.*q - alpha) + c   (solver_socp_inPALM.m:194, solver_wsocp_inPALM.m:200)
 int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *alpha, const double *cvec,
                const double *weight, const double *u0_prev, double *rhs, hipStream_t st);

@@ -24,9 +24,12 @@ struct Slab {
     // staging for what this slab sends to the RIGHT neighbour
     double *send_plane = nullptr, *send_bx = nullptr, *send_by = nullptr;
     KktWork kw{};
+    // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
+    double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
+    FusedGeom fg{};
 };
 
-enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_COUNT };
+enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_FUSED_A, PH_FUSED_B, PH_MATERIALISE, PH_COUNT };
 
 struct Solver {
     dotsocp_problem prob{};
@@ -58,6 +61,8 @@ struct Solver {
 
     // ---- profiling (HIP events on the launch stream) ----
     bool profiling = false;
+    bool fused = true;       // DOTSOCP_FUSED=0 selects the unfused reference dataflow (z stored, 3 cone passes)
+    bool deferred = false;   // fused path: beta still holds beta^{k-1}; z is not materialised
     struct Pending { hipEvent_t a, b; int phase; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
@@ -79,6 +84,7 @@ struct Solver {
     int phase_z();
     int phase_q();
     int phase_mult();
+    int materialise();
     int kkt_sums(double *S);
     int kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk);
     int scale_state(double a_mul, double a_div, double q_div, bool with_c);

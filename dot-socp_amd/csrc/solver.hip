@@ -43,6 +43,7 @@ Solver::~Solver() {
         dfree(s.a0_prev); dfree(s.a0w_prev); dfree(s.btail_bx); dfree(s.btail_by);
         dfree(s.send_plane); dfree(s.send_bx); dfree(s.send_by);
         dfree(s.kw.partials); dfree(s.kw.sums);
+        dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy);
     }
     dct_plan_destroy(py); dct_plan_destroy(px); dct_plan_destroy(pt);
     dfree(cy); dfree(cx); dfree(ct);
@@ -86,6 +87,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
         set_error("in-process multi-slab mode is not available in this build");
         return DOTSOCP_EINVAL;
     }
+    if (const char *e = getenv("DOTSOCP_FUSED")) fused = (atoi(e) != 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no HIP device available (libdotsocp has no CPU fallback)");
@@ -127,6 +129,18 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
         DS_HIP(hipMemsetAsync(s.z, 0, sizeof(double) * 10 * g.Nz, stream));
         DS_HIP(hipMemsetAsync(s.beta, 0, sizeof(double) * 10 * g.Nz, stream));
         DS_HIP(hipMemsetAsync(s.c, 0, sizeof(double) * g.Nphi, stream));
+        if (fused) {
+            fused_geometry(g, s.fg);
+            DS_CHECK(dmalloc(&s.q_old, g.NqAlloc));
+            DS_CHECK(dmalloc(&s.q2, g.NqAlloc));
+            DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
+            DS_CHECK(dmalloc(&s.sx, s.fg.sx_len));
+            DS_CHECK(dmalloc(&s.sy, s.fg.sy_len));
+            DS_HIP(hipMemsetAsync(s.q_old, 0, sizeof(double) * g.NqAlloc, stream));
+            DS_HIP(hipMemsetAsync(s.q2, 0, sizeof(double) * g.NqAlloc, stream));
+            DS_HIP(hipMemsetAsync(s.sx, 0, sizeof(double) * s.fg.sx_len, stream));
+            DS_HIP(hipMemsetAsync(s.sy, 0, sizeof(double) * s.fg.sy_len, stream));
+        }
         s.kw.maxBlocks = kkt_partials_needed(g);
         DS_CHECK(dmalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT));
         DS_CHECK(dmalloc(&s.kw.sums, S_COUNT));
@@ -200,6 +214,7 @@ int Solver::download(int field, double *host) {
     DS_ARG(field_len(field, false) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
     DS_HIP(hipSetDevice(device));
+    if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) DS_CHECK(materialise());
     const i64 NzG = ny * nx * (nt - 1);
     const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * nt;
     for (auto &s : slabs) {
@@ -384,9 +399,32 @@ int Solver::phase_phi() {
 
 int Solver::phase_z() {
     for (auto &s : slabs) {
-        prof_begin(PH_PROJ);
-        DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, stream));
-        prof_end(PH_PROJ);
+        if (!fused) {
+            prof_begin(PH_PROJ);
+            DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, stream));
+            prof_end(PH_PROJ);
+            continue;
+        }
+        FusedArgs a{};
+        a.q = s.q;
+        a.q2 = s.q2;
+        a.sx = s.sx;
+        a.sy = s.sy;
+        if (deferred) {
+            // beta^k = beta^{k-1} + tau (z^k - BF q^k - d) folded into this iteration's projection
+            a.q_old = s.q_old;
+            a.beta_in = s.beta;
+            a.beta_out = s.beta2;
+            prof_begin(PH_FUSED_B);
+            DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, stream));
+            prof_end(PH_FUSED_B);
+            std::swap(s.beta, s.beta2);
+        } else {
+            a.beta_in = s.beta;
+            prof_begin(PH_FUSED_A);
+            DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, stream));
+            prof_end(PH_FUSED_A);
+        }
     }
     return 0;
 }
@@ -394,18 +432,48 @@ int Solver::phase_z() {
 int Solver::phase_q() {
     for (auto &s : slabs) {
         prof_begin(PH_QSTEP);
-        DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
+        if (!fused) {
+            DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
+        } else {
+            // q^{k+1} goes to the buffer that held q^{k-1}; q^k is kept for the deferred beta update
+            DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.q_old,
+                                        s.alpha, stream));
+            std::swap(s.q, s.q_old);
+        }
         prof_end(PH_QSTEP);
     }
     return 0;
 }
 
 int Solver::phase_mult() {
+    if (fused) {
+        deferred = true;     // the multiplier step is executed by the next fused pass (or by materialise())
+        return 0;
+    }
     for (auto &s : slabs) {
         prof_begin(PH_BETA);
         DS_CHECK(launch_beta_update(s.g, lc, s.q, s.z, s.beta, stream));
         prof_end(PH_BETA);
     }
+    return 0;
+}
+
+// Fused path only: execute the pending multiplier step and store z (solver_socp_inPALM.m:199,
+// 212-215) so that beta, z are the iterates the KKT block, the rescale block and the outputs see.
+int Solver::materialise() {
+    if (!fused || !deferred) return 0;
+    for (auto &s : slabs) {
+        FusedArgs a{};
+        a.q_old = s.q_old;
+        a.q = s.q;
+        a.beta_in = s.beta;
+        a.beta_out = s.beta;
+        a.z_out = s.z;
+        prof_begin(PH_MATERIALISE);
+        DS_CHECK(launch_cone_fused(2, s.g, lc, s.fg, a, stream));
+        prof_end(PH_MATERIALISE);
+    }
+    deferred = false;
     return 0;
 }
 
@@ -432,6 +500,7 @@ int Solver::rescale_block() {
     double normPhis = 0, normAlps = 0;
     auto norms = [&](double &nPhis, double &nAlps) -> int {
         double S[S_COUNT];
+        DS_CHECK(materialise());
         DS_CHECK(kkt_sums(S));
         const double sh = sqrt(h);
         const double normPhi = sh * sqrt(S[S_PHI2]), normQ = sh * sqrt(S[S_Q2]), normZ = sh * sqrt(S[S_Z2]);
@@ -500,6 +569,7 @@ static void adjust_lagrangian_param(double &sigma, double xi, double &factor) { 
 // solver_socp_inPALM.m:222-323
 int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
     double S[S_COUNT];
+    DS_CHECK(materialise());
     prof_begin(PH_KKT);
     DS_CHECK(kkt_sums(S));
     prof_end(PH_KKT);
@@ -595,6 +665,7 @@ int Solver::run(i64 n_iters, i64 *done) {
 int Solver::finish(dotsocp_result *res) {
     if (!begun) { set_error("finish() before begin()"); return DOTSOCP_ESTATE; }
     DS_HIP(hipSetDevice(device));
+    DS_CHECK(materialise());
     DS_HIP(hipStreamSynchronize(stream));
     DS_CHECK(prof_flush());
     finished = true;
@@ -606,9 +677,9 @@ int Solver::finish(dotsocp_result *res) {
         res->dScale = dScale;
         // device time per step (HIP events) when profiling is on; Total_Time is host wall time
         res->times[0] = (phase_ms[PH_RHS] + phase_ms[PH_POISSON]) * 1e-3;
-        res->times[1] = phase_ms[PH_PROJ] * 1e-3;
+        res->times[1] = (phase_ms[PH_PROJ] + phase_ms[PH_FUSED_A] + phase_ms[PH_FUSED_B]) * 1e-3;
         res->times[2] = phase_ms[PH_QSTEP] * 1e-3;
-        res->times[3] = phase_ms[PH_BETA] * 1e-3;
+        res->times[3] = (phase_ms[PH_BETA] + phase_ms[PH_MATERIALISE]) * 1e-3;
         res->times[4] = phase_ms[PH_KKT] * 1e-3;
         res->times[5] = elapsed();
         res->times[6] = (double)it;

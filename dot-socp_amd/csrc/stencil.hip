@@ -179,6 +179,79 @@ int launch_qstep(const Grid &g, const LoopCoef &c, const double *phi, const doub
                   : launch_qstep_t<false>(g, c, phi, z, beta, weight, tail_bx, tail_by, q, alpha, st);
 }
 
+// q-step on the adjoint sums produced by the fused cone kernel (fused.hip): q2 already holds
+// sf * sum for tile-interior edges and the own tile's raw partial for tile-boundary edges.
+template <bool WEIGHTED, int SEG>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef c, FusedGeom fg,
+                                                                 const double *__restrict__ phi,
+                                                                 const double *__restrict__ q2v,
+                                                                 const double *__restrict__ sx,
+                                                                 const double *__restrict__ sy,
+                                                                 const double *__restrict__ weight,
+                                                                 const double *__restrict__ tail_bx,
+                                                                 const double *__restrict__ tail_by,
+                                                                 double *__restrict__ q, double *__restrict__ alpha) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    const i64 tl = blockIdx.z;
+    const i64 node = y + g.ny * (x + g.nx * tl);
+    if (SEG == 0) {
+        if (y >= g.ny || x >= g.nx) return;
+        double tmp = (-c.at) * phi[node];
+        tmp += c.at * phi[node + g.plane];
+        q_update<WEIGHTED>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha);
+    } else {
+        const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
+        const double dc = tbnd ? c.c2 : c.c1;
+        const double di = tbnd ? c.dinv2 : c.dinv1;
+        if (SEG == 1) {
+            if (y >= g.ny || x >= g.nx - 1) return;
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            double tmp = (-c.ax) * phi[node];
+            tmp += c.ax * phi[node + g.ny];
+            double q2 = q2v[e];
+            if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
+            if (tl == 0 && !g.first) q2 += c.sf * tail_bx[y + g.ny * x];
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+        } else {
+            if (y >= g.ny - 1 || x >= g.nx) return;
+            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            double tmp = (-c.ay) * phi[node];
+            tmp += c.ay * phi[node + 1];
+            double q2 = q2v[e];
+            if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
+            if (tl == 0 && !g.first) q2 += c.sf * tail_by[y + (g.ny - 1) * x];
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+        }
+    }
+}
+
+template <bool WEIGHTED>
+static int launch_qstep_fused_t(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi,
+                                const double *q2, const double *sx, const double *sy, const double *weight,
+                                const double *tail_bx, const double *tail_by, double *q, double *alpha,
+                                hipStream_t st) {
+    dim3 blk(TILE_Y, TILE_X);
+    if (g.Nz > 0)
+        hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 0>), tile_grid(g, g.ncl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
+                           tail_bx, tail_by, q, alpha);
+    if (g.bxLayer > 0)
+        hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
+                           tail_bx, tail_by, q, alpha);
+    if (g.byLayer > 0)
+        hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 2>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
+                           tail_bx, tail_by, q, alpha);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                       const double *sx, const double *sy, const double *weight, const double *tail_bx,
+                       const double *tail_by, double *q_out, double *alpha, hipStream_t st) {
+    return weight ? launch_qstep_fused_t<true>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st)
+                  : launch_qstep_fused_t<false>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st);
+}
+
 // x = x * mul / div  (left to right, like `alpha * dScale2 / cScale2^2`, solver_socp_inPALM.m:170-178,312-314)
 __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, i64 n, double mul, double div, int use_mul) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {

@@ -17,6 +17,14 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("phi", "q", "z", "alpha", "beta")
 
 
+@pytest.fixture(params=["fused", "unfused"], autouse=True)
+def _dataflow(request, monkeypatch):
+    """Every solver test runs on both device dataflows: the fused cone kernel (deferred multiplier
+    update, z never stored -- the production path) and the unfused one that stores z and mirrors the
+    reference's three cone passes (DOTSOCP_FUSED=0)."""
+    monkeypatch.setenv("DOTSOCP_FUSED", "1" if request.param == "fused" else "0")
+
+
 def _gpu_level(rho0, rho1, nt, opts, method="inPALM", weight=None):
     dim = 2 if np.ndim(rho0) == 2 else 1
     var, model = D.initialize(rho0, rho1, nt)
