@@ -11,6 +11,7 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdint>
 #include <vector>
 
 namespace dotsocp {
@@ -93,118 +94,314 @@ void dct_plan_destroy(DctPlan *p) {
 // axis 0: nin = 1, outerStride = n;  axis 1: nin = n0, outerStride = n0*n1;  axis 2: nin = n0*n1.
 struct LineMap {
     i64 nin, outerStride, nLines;
-    __device__ __forceinline__ i64 addr(i64 L, i64 k) const { return (L % nin) + (L / nin) * outerStride + k * nin; }
+    __device__ __forceinline__ i64 base(i64 L) const { return (L % nin) + (L / nin) * outerStride; }
+    __device__ __forceinline__ i64 addr(i64 L, i64 k) const { return base(L) + k * nin; }
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-__device__ __forceinline__ unsigned bitrev(unsigned k, int lg) { return __brev(k) >> (32 - lg); }
+__device__ __forceinline__ int bitrev(int k, int lg) { return (int)(__brev((unsigned)k) >> (32 - lg)); }
 
 #define DCT_THREADS 256
-#define DCT_PAD 1   // complex elements of padding per LDS row
+#define DCT_WAVES 4
+// LDS rows are padded by one complex element every 16 (stride-16 accesses of the grouped FFT
+// stages and the bit-reversed reads then spread over the banks instead of piling onto one).
+__device__ __host__ __forceinline__ int padi(int p) { return p + (p >> 4); }
+__device__ __host__ __forceinline__ int row_stride(int n) { return n + (n >> 4) + 1; }
 
-// In-LDS radix-2 decimation-in-frequency FFT of `npairs` rows of length n (natural order in,
-// bit-reversed order out).
-__device__ __forceinline__ void fft_dif_lds(double2 *buf, int npairs, int n, int lg, int rowStride,
-                                            const double2 *__restrict__ tw) {
-    const int halfn = n >> 1;
-    const int total = npairs * halfn;
-    for (int s = lg - 1; s >= 0; --s) {
-        const int half = 1 << s;
-        const int twStride = halfn >> s;   // n / (2*half)
-        for (int b = threadIdx.x; b < total; b += DCT_THREADS) {
-            const int row = b / halfn;
-            const int ii = b - row * halfn;
-            const int j = ii & (half - 1);
-            const int i = ((ii - j) << 1) + j;
-            double2 *r = buf + row * rowStride;
-            const double2 a = r[i], bb = r[i + half];
-            const double2 w = tw[j * twStride];
-            r[i] = make_double2(a.x + bb.x, a.y + bb.y);
-            r[i + half] = cmul(make_double2(a.x - bb.x, a.y - bb.y), w);
-        }
-        __syncthreads();
+// LDS hand-off between the lanes of ONE wavefront: DS operations of a wave execute in order, so
+// draining the wave's outstanding LDS operations is all the synchronisation that is needed.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// d * exp(-2 pi i t / 16), t in [0, 8): the constant part of the twiddles inside a register group
+__device__ __forceinline__ double2 mul_w16(double2 d, int t) {
+    const double h = 0.70710678118654752440;   // cos(pi/4)
+    const double c1 = 0.92387953251128675613;  // cos(pi/8)
+    const double s1 = 0.38268343236508977173;  // sin(pi/8)
+    switch (t) {
+        case 0: return d;
+        case 1: return make_double2(d.x * c1 + d.y * s1, d.y * c1 - d.x * s1);
+        case 2: return make_double2(h * (d.x + d.y), h * (d.y - d.x));
+        case 3: return make_double2(d.x * s1 + d.y * c1, d.y * s1 - d.x * c1);
+        case 4: return make_double2(d.y, -d.x);
+        case 5: return make_double2(d.y * c1 - d.x * s1, -(d.x * c1 + d.y * s1));
+        case 6: return make_double2(h * (d.y - d.x), -h * (d.x + d.y));
+        default: return make_double2(d.y * s1 - d.x * c1, -(d.x * s1 + d.y * c1));
     }
 }
 
-// LINE_FAST: consecutive threads walk consecutive lines (strided axes); otherwise consecutive k.
-template <bool INVERSE, bool LINE_FAST>
-__global__ void __launch_bounds__(DCT_THREADS) k_dct_pow2(const double *__restrict__ src, double *__restrict__ dst,
-                                                           LineMap map, int n, int lg, int TL,
-                                                           const double2 *__restrict__ tw,
-                                                           const double2 *__restrict__ ww) {
-    extern __shared__ double2 buf[];
-    const int rowStride = n + DCT_PAD;
-    const int npairs = TL >> 1;
-    const i64 L0 = (i64)blockIdx.x * TL;
-    const int total = TL * n;
-    // ---- load ----
-    for (int e = threadIdx.x; e < total; e += DCT_THREADS) {
-        int l, k;
-        if (LINE_FAST) { l = e % TL; k = e / TL; } else { k = e % n; l = e / n; }
-        const i64 L = L0 + l;
-        const double v = (L < map.nLines) ? src[map.addr(L, k)] : 0.0;
-        // forward: Makhoul reordering v[j] = x[2j], v[n-1-j] = x[2j+1] (mirt_dctn.m:71);
-        // inverse: natural order first, combined below
-        const int pos = INVERSE ? k : ((k & 1) ? (n - 1 - (k >> 1)) : (k >> 1));
-        ((double *)&buf[(l >> 1) * rowStride + pos])[l & 1] = v;
+// One group of LR radix-2 decimation-in-frequency stages done in registers: the lane owns the
+// R = 2^LR elements base + m * (S/R) of one sub-transform of span S = 2^sl and performs the
+// butterflies of spans S, S/2, ..., S/2^(LR-1) on them (same data flow as LR passes of the
+// textbook in-place radix-2 DIF, so the output order is plain bit reversal).
+template <int LR>
+__device__ __forceinline__ void dif_group(double2 *__restrict__ row, int sl, int bidx, int lg,
+                                          const double2 *__restrict__ tw) {
+    constexpr int R = 1 << LR;
+    const int strideLog = sl - LR;
+    const int j = bidx & ((1 << strideLog) - 1);
+    const int base = ((bidx >> strideLog) << sl) + j;
+    double2 x[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = row[padi(base + (m << strideLog))];
+    const int tj = j << (lg - sl);   // j * N / S
+#pragma unroll
+    for (int u = 0; u < LR; ++u) {
+        const int hm = R >> (u + 1);
+        const double2 bu = tw[tj << u];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            if ((m / hm) & 1) continue;
+            const int mm = m % hm;
+            const double2 a = x[m], b = x[m + hm];
+            x[m] = make_double2(a.x + b.x, a.y + b.y);
+            double2 d = make_double2(a.x - b.x, a.y - b.y);
+            d = mul_w16(d, (mm << u) * (16 / R));
+            x[m + hm] = cmul(d, bu);
+        }
     }
-    __syncthreads();
-    if (INVERSE) {
-        // G[k] = (ww[k] X[k] + conj(ww[n-k]) X[n-k]) / 2, so that fft(G) = real(fft(ww .* X))
-        // (mirt_idctn.m:109,119-120); rows hold Xa + i Xb elementwise.
-        const int halfn = n >> 1;
-        for (int b = threadIdx.x; b < npairs * (halfn + 1); b += DCT_THREADS) {
-            const int row = b / (halfn + 1);
-            const int k = b - row * (halfn + 1);
-            double2 *r = buf + row * rowStride;
-            if (k == 0) {
-                const double w0 = ww[0].x;
-                r[0] = make_double2(w0 * r[0].x, w0 * r[0].y);
-            } else {
-                const int m = n - k;
-                const double2 xk = r[k], xm = r[m];          // (Xa[k], Xb[k]), (Xa[m], Xb[m])
-                const double2 wk = ww[k], wm = ww[m];
-                // Ga[k] = (wk*Xa[k] + conj(wm)*Xa[m])/2 ; Gb likewise ; G = Ga + i Gb
-                const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
-                const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
-                r[k] = make_double2(gar - gbi, gai + gbr);
-                if (m != k) {
-                    const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
-                    const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
-                    r[m] = make_double2(har - hbi, hai + hbr);
-                }
+#pragma unroll
+    for (int m = 0; m < R; ++m) row[padi(base + (m << strideLog))] = x[m];
+}
+
+// FFT of the `nrows` = 2^lrw complex rows (length n = 2^lg) owned by the CALLING WAVE, in LDS:
+// natural order in, bit-reversed order out; ceil(lg/4) register groups with a wave-level LDS
+// hand-off after each (no workgroup barrier).
+__device__ __forceinline__ void fft_rows_wave(double2 *rows, int lrw, int lg, int rowStride, int lane,
+                                              const double2 *__restrict__ tw) {
+    const int nst = (lg + 3) >> 2;
+    const int baseBits = lg / nst, extra = lg % nst;
+    int sl = lg;
+    for (int st = 0; st < nst; ++st) {
+        const int lr = baseBits + (st < extra ? 1 : 0);
+        const int lpr = lg - lr;                        // log2(butterflies per row)
+        const int total = 1 << (lrw + lpr);
+        for (int b = lane; b < total; b += 64) {
+            double2 *r = rows + (b >> lpr) * rowStride;
+            const int bidx = b & ((1 << lpr) - 1);
+            switch (lr) {
+                case 4: dif_group<4>(r, sl, bidx, lg, tw); break;
+                case 3: dif_group<3>(r, sl, bidx, lg, tw); break;
+                case 2: dif_group<2>(r, sl, bidx, lg, tw); break;
+                default: dif_group<1>(r, sl, bidx, lg, tw); break;
             }
         }
-        __syncthreads();
+        sl -= lr;
+        wave_lds_sync();
     }
-    fft_dif_lds(buf, npairs, n, lg, rowStride, tw);
-    // ---- store ----
-    for (int e = threadIdx.x; e < total; e += DCT_THREADS) {
-        int l, k;
-        if (LINE_FAST) { l = e % TL; k = e / TL; } else { k = e % n; l = e / n; }
-        const i64 L = L0 + l;
-        if (L >= map.nLines) continue;
-        const double2 *r = buf + (l >> 1) * rowStride;
-        double out;
-        if (!INVERSE) {
-            // X[k] = real(ww[k] * V[k]) per line; V_a = (V[k] + conj(V[n-k]))/2, V_b = (V[k] - conj(V[n-k]))/(2i)
-            const double2 vk = r[bitrev((unsigned)k, lg)];
-            const double2 vm = r[bitrev((unsigned)((n - k) & (n - 1)), lg)];
-            const double2 w = ww[k];
-            double vr, vi;
-            if ((l & 1) == 0) { vr = 0.5 * (vk.x + vm.x); vi = 0.5 * (vk.y - vm.y); }
-            else              { vr = 0.5 * (vk.y + vm.y); vi = -0.5 * (vk.x - vm.x); }
-            out = w.x * vr - w.y * vi;
-        } else {
-            // x[2j] = v[j], x[2j+1] = v[n-1-j]   (mirt_idctn.m:71-73,120)
-            const int srcp = (k & 1) ? (n - 1 - (k >> 1)) : (k >> 1);
-            const double2 v = r[bitrev((unsigned)srcp, lg)];
-            out = (l & 1) ? v.y : v.x;
+}
+
+// Makhoul reordering v[j] = x[2j], v[n-1-j] = x[2j+1] (mirt_dctn.m:71) -- also the output
+// reordering of the inverse (mirt_idctn.m:71-73,120).
+__device__ __forceinline__ int makhoul(int k, int n) { return (k & 1) ? (n - 1 - (k >> 1)) : (k >> 1); }
+
+// Inverse pre-processing on the calling wave's rows (natural order, Xa + i Xb elementwise):
+//   G[k] = (ww[k] X[k] + conj(ww[n-k]) X[n-k]) / 2, so that fft(G) = real(fft(ww .* X))
+//   (mirt_idctn.m:109,119-120).  k and n-k are handled by the same lane.
+__device__ __forceinline__ void idct_combine_wave(double2 *rows, int lrw, int lg, int rowStride, int lane,
+                                                  const double2 *__restrict__ ww) {
+    const int n = 1 << lg, lh = lg - 1;
+    const int total = 1 << (lrw + lh);
+    for (int b = lane; b < total; b += 64) {
+        double2 *r = rows + (b >> lh) * rowStride;
+        const int k = (b & ((1 << lh) - 1)) + 1;          // 1 .. n/2
+        const int m = n - k;
+        const double2 xk = r[padi(k)], xm = r[padi(m)];
+        const double2 wk = ww[k], wm = ww[m];
+        const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
+        const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
+        r[padi(k)] = make_double2(gar - gbi, gai + gbr);
+        if (m != k) {
+            const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
+            const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
+            r[padi(m)] = make_double2(har - hbi, hai + hbr);
         }
-        dst[map.addr(L, k)] = out;
+    }
+    if (lane < (1 << lrw)) {
+        double2 *r = rows + lane * rowStride;
+        const double w0 = ww[0].x;
+        r[0] = make_double2(w0 * r[0].x, w0 * r[0].y);
+    }
+    wave_lds_sync();
+}
+
+// (Xa[k], Xb[k]) = real(ww[k] * V_{a,b}[k]) from the bit-reversed FFT of va + i vb:
+// V_a = (V[k] + conj(V[n-k])) / 2, V_b = (V[k] - conj(V[n-k])) / (2i)   (mirt_dctn.m:130)
+__device__ __forceinline__ double2 dct_post(const double2 *__restrict__ r, int k, int n, int lg,
+                                            const double2 *__restrict__ ww) {
+    const double2 vk = r[padi(bitrev(k, lg))];
+    const double2 vm = r[padi(bitrev((n - k) & (n - 1), lg))];
+    const double2 w = ww[k];
+    const double ar = 0.5 * (vk.x + vm.x), ai = 0.5 * (vk.y - vm.y);
+    const double br = 0.5 * (vk.y + vm.y), bi = -0.5 * (vk.x - vm.x);
+    return make_double2(w.x * ar - w.y * ai, w.x * br - w.y * bi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Axis 0 (lines contiguous in memory): every wave works alone on its own 2^lrw complex rows
+// (pairs of consecutive lines) -- 16-byte global accesses, no workgroup barrier at all.
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ void __launch_bounds__(DCT_THREADS) k_dct_axis0(const double *__restrict__ src, double *__restrict__ dst,
+                                                            i64 nLines, int lg, int lrw,
+                                                            const double2 *__restrict__ tw,
+                                                            const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    const int n = 1 << lg, lh = lg - 1;
+    const int rowStride = row_stride(n);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rw = 1 << lrw;
+    double2 *rows = lds + (wave << lrw) * rowStride;
+    const i64 pair0 = ((i64)blockIdx.x * DCT_WAVES + wave) << lrw;      // first pair of lines of this wave
+    const int total = 1 << (lrw + lh);                                    // (row, j) with j = k / 2
+    // ---- load: two consecutive elements of both lines per lane ----
+    for (int b = lane; b < total; b += 64) {
+        const int rr = b >> lh, j = b & ((1 << lh) - 1);
+        const i64 La = 2 * (pair0 + rr);
+        double2 A = make_double2(0.0, 0.0), B = A;
+        if (La < nLines) A = *(const double2 *)(src + La * n + 2 * j);
+        if (La + 1 < nLines) B = *(const double2 *)(src + (La + 1) * n + 2 * j);
+        double2 *r = rows + rr * rowStride;
+        if (!INVERSE) {
+            r[padi(j)] = make_double2(A.x, B.x);               // x[2j]   -> v[j]
+            r[padi(n - 1 - j)] = make_double2(A.y, B.y);       // x[2j+1] -> v[n-1-j]
+        } else {
+            r[padi(2 * j)] = make_double2(A.x, B.x);
+            r[padi(2 * j + 1)] = make_double2(A.y, B.y);
+        }
+    }
+    wave_lds_sync();
+    if (INVERSE) idct_combine_wave(rows, lrw, lg, rowStride, lane, ww);
+    fft_rows_wave(rows, lrw, lg, rowStride, lane, tw);
+    // ---- store ----
+    for (int b = lane; b < total; b += 64) {
+        const int rr = b >> lh, j = b & ((1 << lh) - 1);
+        const i64 La = 2 * (pair0 + rr);
+        const double2 *r = rows + rr * rowStride;
+        double2 A, B;
+        if (!INVERSE) {
+            const double2 p0 = dct_post(r, 2 * j, n, lg, ww), p1 = dct_post(r, 2 * j + 1, n, lg, ww);
+            A = make_double2(p0.x, p1.x);
+            B = make_double2(p0.y, p1.y);
+        } else {
+            const double2 v0 = r[padi(bitrev(j, lg))], v1 = r[padi(bitrev(n - 1 - j, lg))];
+            A = make_double2(v0.x, v1.x);                      // x[2j] = v[j], x[2j+1] = v[n-1-j]
+            B = make_double2(v0.y, v1.y);
+        }
+        if (La < nLines) *(double2 *)(dst + La * n + 2 * j) = A;
+        if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * n + 2 * j) = B;
+    }
+    (void)rw;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strided axes (x, t): the workgroup stages 2^lp complex rows = 2^(lp+1) lines that are
+// CONSECUTIVE in memory, loads / stores them cooperatively (VEC: one 16-byte access carries both
+// lines of a pair), and every wave runs the FFT of its own rows between the two barriers.
+// TSOLVE: forward DCT, division by the spectral kernel, inverse DCT in one pass (t axis).
+// ---------------------------------------------------------------------------------------------
+struct SolveArgs {
+    i64 ny, x0;            // TSOLVE: line L is column (y, x) = (L % ny, x0 + L / ny)
+    double kscale;
+    const double *cy, *cx, *ct;
+};
+
+template <int MODE /*0 fwd, 1 inv, 2 t-solve*/, bool VEC>
+__global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__restrict__ src, double *__restrict__ dst,
+                                                              LineMap map, int lg, int lp, SolveArgs sa,
+                                                              const double2 *__restrict__ tw,
+                                                              const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    const int n = 1 << lg;
+    const int rowStride = row_stride(n);
+    const int npairs = 1 << lp;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const i64 L0 = (i64)blockIdx.x << (lp + 1);
+    // rows of this wave: npairs / 4 each (all rows go to the first waves when npairs < 4)
+    const int lrw = (lp >= 2) ? lp - 2 : 0;
+    const bool waveActive = (wave << lrw) < npairs;
+    double2 *rows = lds + (wave << lrw) * rowStride;
+    double2 *bufB = lds + npairs * rowStride;                 // TSOLVE only
+    // ---- cooperative load ----
+    if (VEC) {
+        const int r = tid & (npairs - 1);
+        const i64 L = L0 + 2 * r;
+        const bool ok = L < map.nLines;
+        const i64 lb = ok ? map.base(L) : 0;
+        for (int k = tid >> lp; k < n; k += DCT_THREADS >> lp) {
+            const double2 g = ok ? *(const double2 *)(src + lb + (i64)k * map.nin) : make_double2(0.0, 0.0);
+            lds[r * rowStride + padi(MODE == 1 ? k : makhoul(k, n))] = g;
+        }
+    } else {
+        const int l = tid & (2 * npairs - 1);
+        const i64 L = L0 + l;
+        const bool ok = L < map.nLines;
+        const i64 lb = ok ? map.base(L) : 0;
+        for (int k = tid >> (lp + 1); k < n; k += DCT_THREADS >> (lp + 1)) {
+            const double g = ok ? src[lb + (i64)k * map.nin] : 0.0;
+            ((double *)&lds[(l >> 1) * rowStride + padi(MODE == 1 ? k : makhoul(k, n))])[l & 1] = g;
+        }
+    }
+    __syncthreads();
+    if (waveActive) {
+        if (MODE == 1) idct_combine_wave(rows, lrw, lg, rowStride, lane, ww);
+        fft_rows_wave(rows, lrw, lg, rowStride, lane, tw);
+        if (MODE == 2) {
+            // spectral division on the wave's own rows, natural order into the second buffer
+            double2 *rowsB = bufB + (wave << lrw) * rowStride;
+            for (int rr = 0; rr < (1 << lrw); ++rr) {
+                i64 La = L0 + 2 * ((wave << lrw) + rr);
+                if (La + 1 >= map.nLines) La = (map.nLines >= 2) ? map.nLines - 2 : 0;
+                const double ea = sa.cy[La % sa.ny] + sa.cx[sa.x0 + La / sa.ny];          // CY + CX of line a
+                const double eb = sa.cy[(La + 1) % sa.ny] + sa.cx[sa.x0 + (La + 1) / sa.ny];
+                for (int k = lane; k < n; k += 64) {
+                    const double ctk = sa.ct[k];
+                    double la = ea + ctk, lb2 = eb + ctk;
+                    if (la == 0.0) la = 1.0;
+                    if (lb2 == 0.0) lb2 = 1.0;
+                    const double2 X = dct_post(rows + rr * rowStride, k, n, lg, ww);
+                    rowsB[rr * rowStride + padi(k)] = make_double2(X.x / (sa.kscale * la), X.y / (sa.kscale * lb2));
+                }
+            }
+            wave_lds_sync();
+            idct_combine_wave(rowsB, lrw, lg, rowStride, lane, ww);
+            fft_rows_wave(rowsB, lrw, lg, rowStride, lane, tw);
+        }
+    }
+    __syncthreads();
+    // ---- cooperative store ----
+    const double2 *out = (MODE == 2) ? bufB : lds;
+    if (VEC) {
+        const int r = tid & (npairs - 1);
+        const i64 L = L0 + 2 * r;
+        if (L < map.nLines) {
+            const i64 lb = map.base(L);
+            const double2 *rr = out + r * rowStride;
+            for (int k = tid >> lp; k < n; k += DCT_THREADS >> lp) {
+                double2 v;
+                if (MODE == 0) v = dct_post(rr, k, n, lg, ww);
+                else v = rr[padi(bitrev(makhoul(k, n), lg))];
+                *(double2 *)(dst + lb + (i64)k * map.nin) = v;
+            }
+        }
+    } else {
+        const int l = tid & (2 * npairs - 1);
+        const i64 L = L0 + l;
+        if (L < map.nLines) {
+            const i64 lb = map.base(L);
+            const double2 *rr = out + (l >> 1) * rowStride;
+            for (int k = tid >> (lp + 1); k < n; k += DCT_THREADS >> (lp + 1)) {
+                double2 v;
+                if (MODE == 0) v = dct_post(rr, k, n, lg, ww);
+                else v = rr[padi(bitrev(makhoul(k, n), lg))];
+                dst[lb + (i64)k * map.nin] = (l & 1) ? v.y : v.x;
+            }
+        }
     }
 }
 
@@ -240,6 +437,75 @@ __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, do
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+#define DCT_LDS_BUDGET (72 * 1024)
+#define DCT_LDS_MAX (160 * 1024)
+
+static int floor_log2(i64 v) {
+    int l = 0;
+    while (((i64)2 << l) <= v) ++l;
+    return l;
+}
+
+// log2 of the complex rows (pairs of lines) a workgroup stages: as many as fit the LDS budget
+// with `nbuf` buffers, a power of two, at most 32 and no more than the problem has; for the
+// strided axes the lines are consecutive in memory, so more rows = wider coalesced segments.
+static int tile_log2_rows(int n, i64 nLines, int nbuf) {
+    const size_t rowBytes = (size_t)row_stride(n) * sizeof(double2) * nbuf;
+    i64 rows = (i64)(DCT_LDS_BUDGET / rowBytes);
+    if (rows < 1) rows = 1;
+    if (rows > 32) rows = 32;
+    const i64 havePairs = (nLines + 1) / 2;
+    int lp = floor_log2(rows);
+    while (lp > 0 && ((i64)1 << lp) > havePairs) --lp;
+    return lp;
+}
+
+template <class K>
+static void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DCT_LDS_MAX);
+}
+
+bool dct_plan_is_pow2(const DctPlan *p) { return p->log2n > 0; }
+
+static int launch_strided(int mode, const DctPlan *p, const double *src, double *dst, const LineMap &map,
+                          const SolveArgs &sa, hipStream_t st) {
+    const int n = (int)p->n, lg = p->log2n;
+    const int lp = tile_log2_rows(n, map.nLines, mode == 2 ? 2 : 1);
+    const size_t lds = ((size_t)(mode == 2 ? 2 : 1) << lp) * row_stride(n) * sizeof(double2);
+    const i64 linesPerBlock = (i64)2 << lp;
+    const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
+    // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
+    const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+#define LAUNCH_STRIDED(M, V)                                                                                   \
+    do {                                                                                                       \
+        static bool once = false;                                                                              \
+        if (!once) { allow_big_lds(k_dct_strided<M, V>); once = true; }                                        \
+        hipLaunchKernelGGL((k_dct_strided<M, V>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, lg, \
+                           lp, sa, p->tw, p->ww);                                                              \
+    } while (0)
+    if (mode == 0) { if (vec) LAUNCH_STRIDED(0, true); else LAUNCH_STRIDED(0, false); }
+    else if (mode == 1) { if (vec) LAUNCH_STRIDED(1, true); else LAUNCH_STRIDED(1, false); }
+    else { if (vec) LAUNCH_STRIDED(2, true); else LAUNCH_STRIDED(2, false); }
+#undef LAUNCH_STRIDED
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nxl, i64 x0, i64 nt,
+                       double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st) {
+    if (p->log2n <= 0 || p->n != nt) {
+        set_error("fused t-axis solve needs a power-of-two nt");
+        return DOTSOCP_EINVAL;
+    }
+    LineMap map;
+    map.nin = ny * nxl;
+    map.outerStride = 0;
+    map.nLines = ny * nxl;
+    if (map.nLines <= 0) return 0;
+    SolveArgs sa{ny, x0, kscale, cy, cx, ct};
+    return launch_strided(2, p, src, dst, map, sa, st);
+}
+
 int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis, int inverse,
                     hipStream_t st) {
     const i64 dims[3] = {n0, n1, n2};
@@ -261,23 +527,26 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
     else if (axis == 1) { map.nin = n0; map.outerStride = n0 * n1; }
     else { map.nin = n0 * n1; map.outerStride = 0; }
     map.nLines = total / n;
-    const bool lineFast = (axis != 0);
+    if (p->log2n > 0 && axis != 0) {
+        SolveArgs sa{};
+        return launch_strided(inverse ? 1 : 0, p, src, dst, map, sa, st);
+    }
     if (p->log2n > 0) {
-        // LDS budget ~64 KiB per workgroup: TL lines of n doubles (as TL/2 complex rows)
-        int TL = (int)(65536 / (n * 8));
-        if (TL > 16) TL = 16;
-        if (TL < 2) TL = 2;
-        TL &= ~1;
-        if ((i64)TL > ((map.nLines + 1) & ~(i64)1)) TL = (int)((map.nLines + 1) & ~(i64)1);
-        const size_t lds = (size_t)(TL / 2) * (n + DCT_PAD) * sizeof(double2);
-        const unsigned blocks = (unsigned)((map.nLines + TL - 1) / TL);
+        // axis 0: each wave owns 2^lrw rows; a workgroup of 4 waves stages 4 * 2^lrw rows
         const int lg = p->log2n;
-#define LAUNCH_POW2(INV, LF)                                                                                       \
-    hipLaunchKernelGGL((k_dct_pow2<INV, LF>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, lg, \
-                       TL, p->tw, p->ww)
-        if (inverse) { if (lineFast) LAUNCH_POW2(true, true); else LAUNCH_POW2(true, false); }
-        else         { if (lineFast) LAUNCH_POW2(false, true); else LAUNCH_POW2(false, false); }
-#undef LAUNCH_POW2
+        int lp = tile_log2_rows((int)n, map.nLines, 1);
+        const int lrw = lp >= 2 ? lp - 2 : 0;
+        const size_t lds = ((size_t)DCT_WAVES << lrw) * row_stride((int)n) * sizeof(double2);
+        const i64 linesPerBlock = (i64)(2 * DCT_WAVES) << lrw;
+        const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
+        static bool once = false;
+        if (!once) { allow_big_lds(k_dct_axis0<false>); allow_big_lds(k_dct_axis0<true>); once = true; }
+        if (inverse)
+            hipLaunchKernelGGL(k_dct_axis0<true>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
+                               p->tw, p->ww);
+        else
+            hipLaunchKernelGGL(k_dct_axis0<false>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
+                               p->tw, p->ww);
     } else {
         if (src == dst) {
             set_error("dense DCT path needs distinct src/dst");
@@ -289,7 +558,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         const size_t lds = (size_t)TL * n * sizeof(double);
         const unsigned blocks = (unsigned)((map.nLines + TL - 1) / TL);
         const double *M = inverse ? p->Cinv : p->Cfwd;
-        if (lineFast)
+        if (axis != 0)
             hipLaunchKernelGGL((k_dct_dense<true>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, TL, M);
         else
             hipLaunchKernelGGL((k_dct_dense<false>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, TL, M);

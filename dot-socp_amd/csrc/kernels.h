@@ -110,6 +110,11 @@ void dct_plan_destroy(DctPlan *p);
 // (n0 fastest), src -> dst.  axis = 0, 1 or 2.  src == dst is allowed for power-of-two lengths only.
 int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis,
                     int inverse, hipStream_t st);
+// Power-of-two nt only: DCT-II along t, spectral division, DCT-III along t in ONE pass over a
+// [ny][nxl][nt] block (x range starting at x0 of the global grid), src -> dst (may alias).
+bool dct_plan_is_pow2(const DctPlan *p);
+int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nxl, i64 x0, i64 nt,
+                       double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st);
 // data[i] /= kscale * lambda(i)  with lambda the DCT eigenvalues of initialize_FFTkernel.m:6-15
 // for global dims (ny, nx, nt); the local block covers x in [x0, x0+nxl) (pencil mode) and all y, t.
 int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl, double kscale,

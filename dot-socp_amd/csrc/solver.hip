@@ -377,9 +377,13 @@ int Solver::poisson(Slab &s, const double *rhs, double *out) {
     double *a = s.w0, *b = s.w1;
     DS_CHECK(launch_dct_axis(py, rhs, b, g.ny, g.nx, g.ntl, 0, 0, stream));
     DS_CHECK(launch_dct_axis(px, b, a, g.ny, g.nx, g.ntl, 1, 0, stream));
-    DS_CHECK(launch_dct_axis(pt, a, b, g.ny, g.nx, g.ntl, 2, 0, stream));
-    DS_CHECK(launch_spectral_divide(b, g.ny, g.nx, g.nt, 0, g.nx, D * D, cy, cx, ct, stream));
-    DS_CHECK(launch_dct_axis(pt, b, a, g.ny, g.nx, g.ntl, 2, 1, stream));
+    if (dct_plan_is_pow2(pt)) {
+        DS_CHECK(launch_dct_t_solve(pt, a, a, g.ny, g.nx, 0, g.nt, D * D, cy, cx, ct, stream));
+    } else {
+        DS_CHECK(launch_dct_axis(pt, a, b, g.ny, g.nx, g.ntl, 2, 0, stream));
+        DS_CHECK(launch_spectral_divide(b, g.ny, g.nx, g.nt, 0, g.nx, D * D, cy, cx, ct, stream));
+        DS_CHECK(launch_dct_axis(pt, b, a, g.ny, g.nx, g.ntl, 2, 1, stream));
+    }
     DS_CHECK(launch_dct_axis(px, a, b, g.ny, g.nx, g.ntl, 1, 1, stream));
     DS_CHECK(launch_dct_axis(py, b, out, g.ny, g.nx, g.ntl, 0, 1, stream));
     return 0;
