@@ -129,39 +129,69 @@ def main():
         ny, nx, nt = 512, 512, 128
     else:
         ny, nx, nt = 1024, 1024, 128
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        raise SystemExit("time-slab multi-GPU mode is not available in this build")
     if D.capi.lib().dotsocp_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libdotsocp has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dist, rccl = None, None
+    if world > 1:
+        # one process per GPU: torch.distributed (RCCL) carries the rendezvous, the barriers and the
+        # max-over-ranks of the timing; the solver's own halo / transpose traffic runs on a second RCCL
+        # communicator inside libdotsocp, created from a unique id broadcast here
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(D.capi.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        rccl = (bytes(uid.cpu().tolist()), rank, world)
+        if args.workload != "dot2d":
+            raise SystemExit("multi-GPU bench runs the dot2d workload")
 
-    var, model, rho0, rho1, weight = build_problem(D, args.workload, ny, nx, nt)
     opts = dict(tau=1.9, sigma=1.0, tol=0.0, maxit=args.warmup + args.steps, scaling=True,
                 ifCheckStepByStep=False, time_limit=1e9)
-    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False)
+    if world == 1:
+        var, model, rho0, rho1, weight = build_problem(D, args.workload, ny, nx, nt)
+    else:
+        weight = None
+        rho0, rho1 = D.get_example_2d("example1", ny, nx)
+        t0s, t1s = D.capi.slab_range(nt, world, rank)
+        var, model = D.initialize_slab(rho0, rho1, nt, t0s, t1s)
+        D.InitialScaling(var, model, True, None, dim=2)
+    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False, rccl=rccl)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     done = ctx.run(args.warmup)
     assert done == args.warmup
     D.capi.check(D.capi.lib().dotsocp_set_profiling(ctx._ctx, 1))
-    ctx.synchronize()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     done = ctx.run(args.steps)
-    ctx.synchronize()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
     assert done == args.steps
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     hist, sigma = ctx.finish(download=False)
     times = {k: ctx.kernel_time(k) for k in ("rhs", "poisson", "cone_fused_a", "cone_fused_b", "cone_proj",
-                                             "qstep", "beta", "materialise", "kkt")}
+                                             "qstep", "beta", "materialise", "kkt", "comm")}
     ctx.close()
 
-    Nz = ny * nx * (nt - 1)
-    Nq = Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt
+    # per-launch sizes of THIS rank's slab (the whole grid at N = 1)
+    t0s, t1s = D.capi.slab_range(nt, world, rank)
+    ntl = t1s - t0s
+    ncl = ntl if t1s < nt else ntl - 1
+    Nz = ny * nx * ncl
+    Nq = Nz + (ny * (nx - 1) + (ny - 1) * nx) * (ncl + 1)
     # Dominant kernel: the fused cone kernel in its steady-state mode (deferred multiplier update +
     # cone projection + adjoint gather).  Algorithmic bytes per launch:
     # beta in + beta out (20 Nz) + q^{k-1}, q^k in (2 Nq) + adjoint sums out (Nq), fp64.
@@ -206,7 +236,10 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,6 @@ from .examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, g
 from .mexops import (mexBFd, mexBFd1d, mexBFdConj, mexBFdConj1d, mexProjSoc, mirt_dctn, mirt_idctn,  # noqa: F401
                      oper_poisson, oper_poisson3dim)
 from .model import (InitialScaling, ModelHandle, VarHandle, check_massConservation, initialize,  # noqa: F401
-                    recover_q, recover_RhoE, recoverOrgVar)
+                    initialize_slab, recover_q, recover_RhoE, recoverOrgVar)
 from .solvers import (InPALMContext, solver_dotsocp1d, solver_dotsocp2d, solver_socp_inPALM,  # noqa: F401
                       solver_wdotsocp2d, solver_wsocp_inPALM)

@@ -109,3 +109,10 @@ def slab_range(nt, world, rank):
     t0, t1 = i64(), i64()
     check(lib().dotsocp_slab_range(nt, world, rank, ctypes.byref(t0), ctypes.byref(t1)))
     return t0.value, t1.value
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId for dotsocp_attach_rccl(); call on rank 0 and broadcast to the others."""
+    buf = (ctypes.c_ubyte * 128)()
+    check(lib().dotsocp_rccl_unique_id(buf))
+    return bytes(buf)

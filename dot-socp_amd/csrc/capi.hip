@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 
+#include "comm.h"
 #include "solver.h"
 
 using namespace dotsocp;
@@ -252,15 +253,19 @@ int dotsocp_slab_range(dotsocp_i64 nt, int world, int rank, dotsocp_i64 *t0, dot
 }
 
 int dotsocp_rccl_unique_id(unsigned char id[128]) {
-    (void)id;
-    set_error("RCCL communicator support is not available in this build");
-    return DOTSOCP_ECOMM;
+    DS_ARG(id != nullptr, "id is NULL");
+    Rccl &api = rccl_api();
+    DS_CHECK(api.load());
+    ncclUniqueId uid;
+    static_assert(sizeof(uid) == 128, "ncclUniqueId is expected to be 128 bytes");
+    DS_NCCL(api.GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof uid);
+    return 0;
 }
 
 int dotsocp_attach_rccl(dotsocp_ctx *ctx, const unsigned char id[128], int rank, int world) {
-    (void)ctx; (void)id; (void)rank; (void)world;
-    set_error("RCCL communicator support is not available in this build");
-    return DOTSOCP_ECOMM;
+    if (!ctx) { set_error("ctx is NULL"); return DOTSOCP_EINVAL; }
+    return ctx->s.attach_rccl(id, rank, world);
 }
 
 #define CTX_OR_FAIL()                                      \
@@ -297,7 +302,7 @@ int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dots
     CTX_OR_FAIL();
     DS_ARG(name != nullptr, "name is NULL");
     static const char *names[PH_COUNT] = {"rhs", "poisson", "cone_proj", "qstep", "beta", "kkt",
-                                          "cone_fused_a", "cone_fused_b", "materialise"};
+                                          "cone_fused_a", "cone_fused_b", "materialise", "comm"};
     for (int i = 0; i < PH_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) {
             const i64 n = ctx->s.phase_launches[i];

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_axis0(const double *__restr
 // TSOLVE: forward DCT, division by the spectral kernel, inverse DCT in one pass (t axis).
 // ---------------------------------------------------------------------------------------------
 struct SolveArgs {
-    i64 ny, x0;            // TSOLVE: line L is column (y, x) = (L % ny, x0 + L / ny)
+    i64 ny, line0, nplane; // TSOLVE: local line L is column (y, x) = (G % ny, G / ny), G = line0 + L, of ny*nx = nplane columns
     double kscale;
     const double *cy, *cx, *ct;
 };
@@ -357,8 +357,10 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
             for (int rr = 0; rr < (1 << lrw); ++rr) {
                 i64 La = L0 + 2 * ((wave << lrw) + rr);
                 if (La + 1 >= map.nLines) La = (map.nLines >= 2) ? map.nLines - 2 : 0;
-                const double ea = sa.cy[La % sa.ny] + sa.cx[sa.x0 + La / sa.ny];          // CY + CX of line a
-                const double eb = sa.cy[(La + 1) % sa.ny] + sa.cx[sa.x0 + (La + 1) / sa.ny];
+                const i64 Ga = sa.line0 + La;
+                const i64 Gb = (Ga + 1 < sa.nplane) ? Ga + 1 : Ga;
+                const double ea = sa.cy[Ga % sa.ny] + sa.cx[Ga / sa.ny];                    // CY + CX of line a
+                const double eb = sa.cy[Gb % sa.ny] + sa.cx[Gb / sa.ny];
                 for (int k = lane; k < n; k += 64) {
                     const double ctk = sa.ct[k];
                     double la = ea + ctk, lb2 = eb + ctk;
@@ -491,18 +493,18 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     return 0;
 }
 
-int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nxl, i64 x0, i64 nt,
-                       double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st) {
+int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nplane, i64 line0, i64 nl,
+                       i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st) {
     if (p->log2n <= 0 || p->n != nt) {
         set_error("fused t-axis solve needs a power-of-two nt");
         return DOTSOCP_EINVAL;
     }
     LineMap map;
-    map.nin = ny * nxl;
+    map.nin = nl;
     map.outerStride = 0;
-    map.nLines = ny * nxl;
+    map.nLines = nl;
     if (map.nLines <= 0) return 0;
-    SolveArgs sa{ny, x0, kscale, cy, cx, ct};
+    SolveArgs sa{ny, line0, nplane, kscale, cy, cx, ct};
     return launch_strided(2, p, src, dst, map, sa, st);
 }
 
@@ -581,6 +583,29 @@ __global__ void __launch_bounds__(256) k_spectral_divide(double *__restrict__ da
     if (lam == 0.0) lam = 1.0;
     const i64 i = y + ny * (x + nxl * t);
     data[i] = data[i] / (kscale * lam);
+}
+
+__global__ void __launch_bounds__(256) k_spectral_divide_pencil(double *__restrict__ data, i64 ny, i64 line0, i64 nl,
+                                                                 i64 nt, double kscale, const double *__restrict__ cy,
+                                                                 const double *__restrict__ cx,
+                                                                 const double *__restrict__ ct) {
+    const i64 L = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 t = blockIdx.y;
+    if (L >= nl) return;
+    const i64 G = line0 + L;
+    double lam = (cy[G % ny] + cx[G / ny]) + ct[t];
+    if (lam == 0.0) lam = 1.0;
+    data[L + nl * t] = data[L + nl * t] / (kscale * lam);
+}
+
+int launch_spectral_divide_pencil(double *data, i64 ny, i64 nplane, i64 line0, i64 nl, i64 nt, double kscale,
+                                  const double *cy, const double *cx, const double *ct, hipStream_t st) {
+    (void)nplane;
+    if (nl * nt <= 0) return 0;
+    dim3 grid((unsigned)((nl + 255) / 256), (unsigned)nt);
+    hipLaunchKernelGGL(k_spectral_divide_pencil, grid, dim3(256), 0, st, data, ny, line0, nl, nt, kscale, cy, cx, ct);
+    DS_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl, double kscale, const double *cy,

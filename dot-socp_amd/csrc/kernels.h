@@ -74,6 +74,12 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *q2, const double *sx, const double *sy, const double *weight,
                        const double *tail_bx, const double *tail_by, double *q_out, double *alpha,
                        hipStream_t st);
+// time-slab mode: complete the adjoint sums of the last owned cell for the right neighbour (values times sf)
+int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,
+                         const double *sy, double *tail_bx, double *tail_by, hipStream_t st);
+// time-slab mode, KKT block: alpha0, w.*alpha0 and raw adjoint partial sums of beta of the last owned cell layer
+int launch_kkt_tail(const Grid &g, const double *alpha, const double *beta, const double *weight, double *a0,
+                    double *a0w, double *bt_bx, double *bt_by, hipStream_t st);
 // rhs = A'(w.*q - alpha) + c   (solver_socp_inPALM.m:194, solver_wsocp_inPALM.m:200)
 int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *alpha, const double *cvec,
                const double *weight, const double *u0_prev, double *rhs, hipStream_t st);
@@ -111,10 +117,14 @@ void dct_plan_destroy(DctPlan *p);
 int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis,
                     int inverse, hipStream_t st);
 // Power-of-two nt only: DCT-II along t, spectral division, DCT-III along t in ONE pass over a
-// [ny][nxl][nt] block (x range starting at x0 of the global grid), src -> dst (may alias).
+// pencil [nl][nt]: the columns line0 .. line0+nl-1 of the ny*nx = nplane (y, x) columns (y fastest),
+// all nt time nodes; src -> dst (may alias).
 bool dct_plan_is_pow2(const DctPlan *p);
-int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nxl, i64 x0, i64 nt,
-                       double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st);
+int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nplane, i64 line0, i64 nl,
+                       i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st);
+// same pencil, non-power-of-two nt: spectral division only (between two dense DCT passes)
+int launch_spectral_divide_pencil(double *data, i64 ny, i64 nplane, i64 line0, i64 nl, i64 nt, double kscale,
+                                  const double *cy, const double *cx, const double *ct, hipStream_t st);
 // data[i] /= kscale * lambda(i)  with lambda the DCT eigenvalues of initialize_FFTkernel.m:6-15
 // for global dims (ny, nx, nt); the local block covers x in [x0, x0+nxl) (pencil mode) and all y, t.
 int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl, double kscale,

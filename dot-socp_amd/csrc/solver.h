@@ -1,6 +1,7 @@
 // Device-resident inPALM/ALG2 loop state (B1 boundary of include/dotsocp.h).
 #pragma once
 #include <chrono>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -8,7 +9,11 @@
 
 namespace dotsocp {
 
+// One time slab (common.h: Grid).  Single-GPU runs have exactly one; `nslabs` > 1 keeps several in
+// one process (the multi-GPU algorithm with device-to-device copies as "communication"); with an
+// RCCL communicator attached the process holds the single slab `rank` of `world`.
 struct Slab {
+    int index = 0;              // global slab number
     Grid g;
     double *phi = nullptr;      // NphiAlloc (owned nodes + halo layer)
     double *q = nullptr;        // NqAlloc
@@ -17,29 +22,38 @@ struct Slab {
     double *beta = nullptr;     // 10 * Nz
     double *c = nullptr;        // Nphi
     double *weight = nullptr;   // NqAlloc (weighted only)
-    double *w0 = nullptr, *w1 = nullptr;   // Poisson work arrays
+    double *w0 = nullptr, *w1 = nullptr;   // Poisson work arrays (slab layout)
+    // Poisson t-axis: this slab's pencil = columns [l0, l0+nl) of the ny*nx (y, x) columns, all nt nodes
+    i64 l0 = 0, nl = 0;
+    double *pencil = nullptr, *pencil2 = nullptr;   // nl * nt each (pencil2: dense / RCCL staging)
+    double *stage = nullptr;                        // Nphi (RCCL pack buffer)
     // halos received from the LEFT neighbour (nullptr on the first slab)
     double *u0_prev = nullptr, *tail_bx = nullptr, *tail_by = nullptr;
     double *a0_prev = nullptr, *a0w_prev = nullptr, *btail_bx = nullptr, *btail_by = nullptr;
-    // staging for what this slab sends to the RIGHT neighbour
-    double *send_plane = nullptr, *send_bx = nullptr, *send_by = nullptr;
+    // staging for what this slab sends to the RIGHT neighbour (nullptr on the last slab)
+    double *send_plane = nullptr, *send_plane2 = nullptr, *send_bx = nullptr, *send_by = nullptr;
     KktWork kw{};
     // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
     double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
     FusedGeom fg{};
 };
 
-enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_FUSED_A, PH_FUSED_B, PH_MATERIALISE, PH_COUNT };
+enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_FUSED_A, PH_FUSED_B, PH_MATERIALISE,
+             PH_COMM, PH_COUNT };
 
 struct Solver {
     dotsocp_problem prob{};
     int device = 0;
     i64 ny = 0, nx = 0, nt = 0;     // internal dims (1-D problems: ny = nx1d, nx = 1)
     hipStream_t stream = nullptr;
-    std::vector<Slab> slabs;
+    std::vector<Slab> slabs;        // the slabs held by THIS process
+    int world = 1;                  // total number of slabs
+    int rank = 0;                   // RCCL mode: this process's slab
+    void *nccl = nullptr;           // ncclComm_t when a communicator is attached
     DctPlan *py = nullptr, *px = nullptr, *pt = nullptr;
     double *cy = nullptr, *cx = nullptr, *ct = nullptr;   // DCT eigenvalue tables (device)
-    double *h_sums = nullptr;       // pinned host buffer [S_COUNT]
+    double *h_sums = nullptr;       // pinned host buffer [S_COUNT + 1]
+    double *d_red = nullptr;        // device buffer for the cross-rank reduction [S_COUNT + 1]
 
     // ---- loop state (mirrors solver_socp_inPALM.m:11-135) ----
     bool begun = false, finished = false, stopped = false;
@@ -58,6 +72,7 @@ struct Solver {
     std::vector<double> hist_kkt, hist_time, hist_iter, hist_gap;   // kkt stored row-wise (7 per entry)
     std::chrono::steady_clock::time_point t_begin;
     double elapsed_prev = 0.0;
+    double elapsed_agreed = 0.0;    // multi-process: max over ranks at the last KKT check
 
     // ---- profiling (HIP events on the launch stream) ----
     bool profiling = false;
@@ -71,6 +86,7 @@ struct Solver {
 
     ~Solver();
     int init(const dotsocp_problem *p, int device, int nslabs);
+    int attach_rccl(const unsigned char *id, int rank, int world);
     int upload(int field, const double *host);
     int download(int field, double *host);
     int begin(const dotsocp_opts *o);
@@ -78,6 +94,10 @@ struct Solver {
     int finish(dotsocp_result *res);
 
     // internals
+    int alloc_slabs(int first, int count);
+    void free_slabs();
+    bool multi() const { return world > 1; }
+    bool remote() const { return nccl != nullptr; }
     int step(bool *brk);
     int rescale_block();
     int phase_phi();
@@ -93,8 +113,14 @@ struct Solver {
     void prof_begin(int phase);
     void prof_end(int phase);
     int prof_flush();
-    int poisson(Slab &s, const double *rhs, double *out);
-    i64 field_len(int field, bool local) const;
+    int poisson_all();
+    int transpose(bool forward);
+    int exchange_q_halo();
+    // every slab with a neighbour in direction `dir` (+1 right, -1 left) sends `count` doubles
+    // from src(slab) to dst(neighbour)
+    typedef std::function<double *(Slab &)> Sel;
+    int shift(int dir, const Sel &src, const Sel &dst, i64 count);
+    i64 field_len(int field) const;
 };
 
 }  // namespace dotsocp

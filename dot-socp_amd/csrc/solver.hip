@@ -1,12 +1,19 @@
 // Host side of the device-resident inPALM / ALG2 loop.  The scalar control flow (sigma rule,
 // rescale triggers, KKT ratios, stop test) restates socp/dot2d/algorithms/solver_socp_inPALM.m
 // (and solver_wsocp_inPALM.m for the weighted variant) line by line; all array work is done by the
-// kernels of cone.hip / stencil.hip / dct.hip / kkt.hip on one HIP stream.
+// kernels of cone.hip / fused.hip / stencil.hip / dct.hip / kkt.hip on one HIP stream.
+//
+// Time-slab mode (world > 1): the grid is cut along t (common.h: Grid).  Per iteration a slab
+// exchanges six ny x nx layers with its neighbours (u0 tail, phi head, adjoint tails, bx/by heads)
+// and the Poisson solve transposes slabs <-> pencils around its t-axis pass.  The same code runs
+// with all slabs in one process (device-to-device copies) or with one slab per process (RCCL).
 #include "solver.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+
+#include "comm.h"
 
 namespace dotsocp {
 
@@ -29,24 +36,36 @@ static int dmalloc(T **p, i64 n) {
     return 0;
 }
 
+static int dzalloc(double **p, i64 n, hipStream_t st) {
+    DS_CHECK(dmalloc(p, n));
+    DS_HIP(hipMemsetAsync(*p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), st));
+    return 0;
+}
+
 static void dfree(void *p) {
     if (p) (void)hipFree(p);
+}
+
+void Solver::free_slabs() {
+    for (auto &s : slabs) {
+        dfree(s.phi); dfree(s.q); dfree(s.alpha); dfree(s.z); dfree(s.beta); dfree(s.c); dfree(s.weight);
+        dfree(s.w0); dfree(s.w1); dfree(s.pencil); dfree(s.pencil2); dfree(s.stage);
+        dfree(s.u0_prev); dfree(s.tail_bx); dfree(s.tail_by);
+        dfree(s.a0_prev); dfree(s.a0w_prev); dfree(s.btail_bx); dfree(s.btail_by);
+        dfree(s.send_plane); dfree(s.send_plane2); dfree(s.send_bx); dfree(s.send_by);
+        dfree(s.kw.partials); dfree(s.kw.sums);
+        dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy);
+    }
+    slabs.clear();
 }
 
 Solver::~Solver() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    for (auto &s : slabs) {
-        dfree(s.phi); dfree(s.q); dfree(s.alpha); dfree(s.z); dfree(s.beta); dfree(s.c); dfree(s.weight);
-        dfree(s.w0); dfree(s.w1);
-        dfree(s.u0_prev); dfree(s.tail_bx); dfree(s.tail_by);
-        dfree(s.a0_prev); dfree(s.a0w_prev); dfree(s.btail_bx); dfree(s.btail_by);
-        dfree(s.send_plane); dfree(s.send_bx); dfree(s.send_by);
-        dfree(s.kw.partials); dfree(s.kw.sums);
-        dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy);
-    }
+    if (nccl) (void)rccl_api().CommDestroy((ncclComm_t)nccl);
+    free_slabs();
     dct_plan_destroy(py); dct_plan_destroy(px); dct_plan_destroy(pt);
-    dfree(cy); dfree(cx); dfree(ct);
+    dfree(cy); dfree(cx); dfree(ct); dfree(d_red);
     if (h_sums) (void)hipHostFree(h_sums);
     for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -73,6 +92,13 @@ int dotsocp_slab_range_impl(i64 nt, int world, int rank, i64 *t0, i64 *t1) {
     return 0;
 }
 
+// pencil j of `world`: columns [l0, l1) of the ny*nx (y, x) columns, boundaries on even columns
+static void pencil_range(i64 plane, int world, int j, i64 *l0, i64 *l1) {
+    auto cut = [&](int k) -> i64 { return (k >= world) ? plane : 2 * ((plane / 2) * k / world); };
+    *l0 = cut(j);
+    *l1 = cut(j + 1);
+}
+
 int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_ARG(p != nullptr, "prob is NULL");
     DS_ARG(p->dim == 1 || p->dim == 2, "prob.dim must be 1 or 2");
@@ -83,11 +109,11 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     nt = p->nt;
     DS_ARG(ny >= 1 && nx >= 1, "grid too small");
     DS_ARG(nslabs >= 1 && nslabs <= nt / 2, "nslabs must be in [1, nt/2]");
-    if (nslabs != 1) {
-        set_error("in-process multi-slab mode is not available in this build");
+    if (const char *e = getenv("DOTSOCP_FUSED")) fused = (atoi(e) != 0);
+    if (nslabs > 1 && !fused) {
+        set_error("time slabs need the fused dataflow (unset DOTSOCP_FUSED=0)");
         return DOTSOCP_EINVAL;
     }
-    if (const char *e = getenv("DOTSOCP_FUSED")) fused = (atoi(e) != 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no HIP device available (libdotsocp has no CPU fallback)");
@@ -96,7 +122,8 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_ARG(dev >= 0 && dev < ndev, "device ordinal out of range");
     DS_HIP(hipSetDevice(dev));
     DS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * S_COUNT));
+    DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
+    DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
     py = dct_plan_create(ny);
     px = dct_plan_create(nx);
     pt = dct_plan_create(nt);
@@ -107,56 +134,202 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_CHECK(make_eig_table(&cy, ny));
     DS_CHECK(make_eig_table(&cx, nx));
     DS_CHECK(make_eig_table(&ct, nt));
-    slabs.resize(nslabs);
-    for (int r = 0; r < nslabs; ++r) {
+    world = nslabs;
+    rank = 0;
+    DS_CHECK(alloc_slabs(0, nslabs));
+    DS_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Solver::alloc_slabs(int first, int count) {
+    free_slabs();
+    slabs.resize(count);
+    const i64 plane = ny * nx;
+    for (int r = 0; r < count; ++r) {
         Slab &s = slabs[r];
+        s.index = first + r;
         i64 t0, t1;
-        dotsocp_slab_range_impl(nt, nslabs, r, &t0, &t1);
+        dotsocp_slab_range_impl(nt, world, s.index, &t0, &t1);
         s.g.set(ny, nx, nt, t0, t1 - t0);
         const Grid &g = s.g;
-        DS_CHECK(dmalloc(&s.phi, g.NphiAlloc));
-        DS_CHECK(dmalloc(&s.q, g.NqAlloc));
-        DS_CHECK(dmalloc(&s.alpha, g.NqAlloc));
-        DS_CHECK(dmalloc(&s.z, 10 * g.Nz));
-        DS_CHECK(dmalloc(&s.beta, 10 * g.Nz));
-        DS_CHECK(dmalloc(&s.c, g.Nphi));
+        DS_CHECK(dzalloc(&s.phi, g.NphiAlloc, stream));
+        DS_CHECK(dzalloc(&s.q, g.NqAlloc, stream));
+        DS_CHECK(dzalloc(&s.alpha, g.NqAlloc, stream));
+        DS_CHECK(dzalloc(&s.z, 10 * g.Nz, stream));
+        DS_CHECK(dzalloc(&s.beta, 10 * g.Nz, stream));
+        DS_CHECK(dzalloc(&s.c, g.Nphi, stream));
         DS_CHECK(dmalloc(&s.w0, g.Nphi));
         DS_CHECK(dmalloc(&s.w1, g.Nphi));
-        if (prob.weighted) DS_CHECK(dmalloc(&s.weight, g.NqAlloc));
-        DS_HIP(hipMemsetAsync(s.phi, 0, sizeof(double) * g.NphiAlloc, stream));
-        DS_HIP(hipMemsetAsync(s.q, 0, sizeof(double) * g.NqAlloc, stream));
-        DS_HIP(hipMemsetAsync(s.alpha, 0, sizeof(double) * g.NqAlloc, stream));
-        DS_HIP(hipMemsetAsync(s.z, 0, sizeof(double) * 10 * g.Nz, stream));
-        DS_HIP(hipMemsetAsync(s.beta, 0, sizeof(double) * 10 * g.Nz, stream));
-        DS_HIP(hipMemsetAsync(s.c, 0, sizeof(double) * g.Nphi, stream));
+        if (prob.weighted) DS_CHECK(dzalloc(&s.weight, g.NqAlloc, stream));
         if (fused) {
             fused_geometry(g, s.fg);
-            DS_CHECK(dmalloc(&s.q_old, g.NqAlloc));
-            DS_CHECK(dmalloc(&s.q2, g.NqAlloc));
+            DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, stream));
+            DS_CHECK(dzalloc(&s.q2, g.NqAlloc, stream));
             DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
-            DS_CHECK(dmalloc(&s.sx, s.fg.sx_len));
-            DS_CHECK(dmalloc(&s.sy, s.fg.sy_len));
-            DS_HIP(hipMemsetAsync(s.q_old, 0, sizeof(double) * g.NqAlloc, stream));
-            DS_HIP(hipMemsetAsync(s.q2, 0, sizeof(double) * g.NqAlloc, stream));
-            DS_HIP(hipMemsetAsync(s.sx, 0, sizeof(double) * s.fg.sx_len, stream));
-            DS_HIP(hipMemsetAsync(s.sy, 0, sizeof(double) * s.fg.sy_len, stream));
+            DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, stream));
+            DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, stream));
         }
         s.kw.maxBlocks = kkt_partials_needed(g);
         DS_CHECK(dmalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT));
         DS_CHECK(dmalloc(&s.kw.sums, S_COUNT));
+        pencil_range(plane, world, s.index, &s.l0, &s.nl);
+        s.nl -= s.l0;
+        if (multi()) {
+            DS_CHECK(dmalloc(&s.pencil, s.nl * nt));
+            DS_CHECK(dmalloc(&s.pencil2, s.nl * nt));
+            DS_CHECK(dmalloc(&s.stage, g.Nphi));
+            if (!g.first) {
+                DS_CHECK(dzalloc(&s.u0_prev, plane, stream));
+                DS_CHECK(dzalloc(&s.a0_prev, plane, stream));
+                DS_CHECK(dzalloc(&s.a0w_prev, plane, stream));
+                DS_CHECK(dzalloc(&s.tail_bx, g.bxLayer, stream));
+                DS_CHECK(dzalloc(&s.btail_bx, g.bxLayer, stream));
+                DS_CHECK(dzalloc(&s.tail_by, g.byLayer, stream));
+                DS_CHECK(dzalloc(&s.btail_by, g.byLayer, stream));
+            }
+            if (!g.last) {
+                DS_CHECK(dzalloc(&s.send_plane, plane, stream));
+                DS_CHECK(dzalloc(&s.send_plane2, plane, stream));
+                DS_CHECK(dzalloc(&s.send_bx, g.bxLayer, stream));
+                DS_CHECK(dzalloc(&s.send_by, g.byLayer, stream));
+            }
+        }
     }
+    return 0;
+}
+
+int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
+    DS_ARG(id != nullptr, "unique id is NULL");
+    DS_ARG(wd >= 1 && rk >= 0 && rk < wd, "bad rank / world");
+    DS_ARG(wd <= nt / 2, "world must not exceed nt/2 time slabs");
+    if (begun || world != 1) { set_error("attach_rccl() must directly follow create(..., nslabs = 1)"); return DOTSOCP_ESTATE; }
+    if (!fused) { set_error("time slabs need the fused dataflow (unset DOTSOCP_FUSED=0)"); return DOTSOCP_EINVAL; }
+    DS_HIP(hipSetDevice(device));
+    Rccl &api = rccl_api();
+    DS_CHECK(api.load());
+    ncclUniqueId uid;
+    static_assert(sizeof(uid) == 128, "ncclUniqueId is expected to be 128 bytes");
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    DS_NCCL(api.CommInitRank(&comm, wd, uid, rk));
+    nccl = comm;
+    world = wd;
+    rank = rk;
+    DS_CHECK(alloc_slabs(rk, 1));
     DS_HIP(hipStreamSynchronize(stream));
     return 0;
 }
 
 // --------------------------------------------------------------------------------------
-// upload / download (host pointers hold the GLOBAL field in the reference layout)
+// neighbour exchanges
+// --------------------------------------------------------------------------------------
+int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
+    if (!multi() || count <= 0) return 0;
+    if (!remote()) {
+        for (size_t i = 0; i + 1 < slabs.size(); ++i) {
+            Slab &from = (dir > 0) ? slabs[i] : slabs[i + 1];
+            Slab &to = (dir > 0) ? slabs[i + 1] : slabs[i];
+            DS_HIP(hipMemcpyAsync(dst(to), src(from), sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+        }
+        return 0;
+    }
+    Rccl &api = rccl_api();
+    Slab &s = slabs[0];
+    const int to = rank + dir, from = rank - dir;
+    DS_NCCL(api.GroupStart());
+    if (to >= 0 && to < world) DS_NCCL(api.Send(src(s), (size_t)count, ncclDouble, to, (ncclComm_t)nccl, stream));
+    if (from >= 0 && from < world) DS_NCCL(api.Recv(dst(s), (size_t)count, ncclDouble, from, (ncclComm_t)nccl, stream));
+    DS_NCCL(api.GroupEnd());
+    return 0;
+}
+
+// first owned bx / by layers of every slab -> halo layer of its left neighbour
+int Solver::exchange_q_halo() {
+    if (!multi()) return 0;
+    prof_begin(PH_COMM);
+    const i64 bxL = slabs[0].g.bxLayer, byL = slabs[0].g.byLayer;
+    DS_CHECK(shift(-1, [](Slab &s) { return s.q + s.g.offBx; },
+                   [](Slab &s) { return s.q + s.g.offBx + s.g.bxLayer * s.g.ntl; }, bxL));
+    DS_CHECK(shift(-1, [](Slab &s) { return s.q + s.g.offBy; },
+                   [](Slab &s) { return s.q + s.g.offBy + s.g.byLayer * s.g.ntl; }, byL));
+    prof_end(PH_COMM);
+    return 0;
+}
+
+// slabs [y][x][t_local] <-> pencils [columns l0..l0+nl)[all t]; data in w0 resp. pencil
+int Solver::transpose(bool forward) {
+    const i64 plane = ny * nx;
+    if (!remote()) {
+        for (auto &s : slabs)
+            for (auto &p : slabs) {
+                double *slabPtr = s.w0 + p.l0;                    // layer pitch plane
+                double *penPtr = p.pencil + p.nl * s.g.t0;        // layer pitch p.nl
+                if (p.nl <= 0) continue;
+                if (forward)
+                    DS_HIP(hipMemcpy2DAsync(penPtr, sizeof(double) * p.nl, slabPtr, sizeof(double) * plane,
+                                            sizeof(double) * p.nl, s.g.ntl, hipMemcpyDeviceToDevice, stream));
+                else
+                    DS_HIP(hipMemcpy2DAsync(slabPtr, sizeof(double) * plane, penPtr, sizeof(double) * p.nl,
+                                            sizeof(double) * p.nl, s.g.ntl, hipMemcpyDeviceToDevice, stream));
+            }
+        return 0;
+    }
+    // one slab per process: pack the part of every peer contiguously, then one send/recv per peer
+    Rccl &api = rccl_api();
+    Slab &s = slabs[0];
+    std::vector<i64> off(world + 1, 0), pl0(world), pnl(world), pt0(world), pntl(world);
+    for (int j = 0; j < world; ++j) {
+        i64 a, b;
+        pencil_range(plane, world, j, &a, &b);
+        pl0[j] = a;
+        pnl[j] = b - a;
+        dotsocp_slab_range_impl(nt, world, j, &a, &b);
+        pt0[j] = a;
+        pntl[j] = b - a;
+        off[j + 1] = off[j] + pnl[j] * s.g.ntl;
+    }
+    if (forward) {
+        for (int j = 0; j < world; ++j)
+            if (pnl[j] > 0)
+                DS_HIP(hipMemcpy2DAsync(s.stage + off[j], sizeof(double) * pnl[j], s.w0 + pl0[j], sizeof(double) * plane,
+                                        sizeof(double) * pnl[j], s.g.ntl, hipMemcpyDeviceToDevice, stream));
+        DS_NCCL(api.GroupStart());
+        for (int j = 0; j < world; ++j) {
+            if (pnl[j] > 0)
+                DS_NCCL(api.Send(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
+            if (s.nl > 0)
+                DS_NCCL(api.Recv(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
+        }
+        DS_NCCL(api.GroupEnd());
+    } else {
+        DS_NCCL(api.GroupStart());
+        for (int j = 0; j < world; ++j) {
+            if (s.nl > 0)
+                DS_NCCL(api.Send(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
+            if (pnl[j] > 0)
+                DS_NCCL(api.Recv(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
+        }
+        DS_NCCL(api.GroupEnd());
+        for (int j = 0; j < world; ++j)
+            if (pnl[j] > 0)
+                DS_HIP(hipMemcpy2DAsync(s.w0 + pl0[j], sizeof(double) * plane, s.stage + off[j], sizeof(double) * pnl[j],
+                                        sizeof(double) * pnl[j], s.g.ntl, hipMemcpyDeviceToDevice, stream));
+    }
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// upload / download.  Host pointers hold the GLOBAL field in the reference layout; with an RCCL
+// communicator attached they hold this process's slab of it (same layout restricted to the owned
+// layers: q = [q0 cells | bx layers | by layers]).
 // --------------------------------------------------------------------------------------
 static const int k1dCols[6] = {0, 5, 6, 7, 8, 9};   // 1-D cone columns inside the 10-plane layout
 
-i64 Solver::field_len(int field, bool) const {
-    const i64 Nz = ny * nx * (nt - 1), Nphi = ny * nx * nt;
-    const i64 Nq = Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt;
+i64 Solver::field_len(int field) const {
+    i64 ntn = nt, ntc = nt - 1;
+    if (remote()) { ntn = slabs[0].g.ntl; ntc = slabs[0].g.ncl; }
+    const i64 Nz = ny * nx * ntc, Nphi = ny * nx * ntn;
+    const i64 Nq = Nz + ny * (nx - 1) * ntn + (ny - 1) * nx * ntn;
     switch (field) {
         case DOTSOCP_F_PHI: case DOTSOCP_F_C: return Nphi;
         case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: return Nq;
@@ -165,94 +338,66 @@ i64 Solver::field_len(int field, bool) const {
     }
 }
 
-int Solver::upload(int field, const double *host) {
-    DS_ARG(host != nullptr, "host pointer is NULL");
-    DS_ARG(field_len(field, false) >= 0, "unknown field");
-    DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "weight uploaded to an unweighted problem");
-    DS_HIP(hipSetDevice(device));
-    const i64 NzG = ny * nx * (nt - 1);
-    const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * nt;
-    for (auto &s : slabs) {
+static int copy_field(Solver &S, int field, double *host, bool up) {
+    const i64 ny = S.ny, nx = S.nx;
+    i64 ntn = S.nt, ntc = S.nt - 1;
+    if (S.remote()) { ntn = S.slabs[0].g.ntl; ntc = S.slabs[0].g.ncl; }
+    const i64 NzG = ny * nx * ntc;
+    const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * ntn;
+    auto cp = [&](double *dev, double *h, i64 n) -> int {
+        if (n <= 0) return 0;
+        if (up) DS_HIP(hipMemcpyAsync(dev, h, sizeof(double) * n, hipMemcpyHostToDevice, S.stream));
+        else DS_HIP(hipMemcpyAsync(h, dev, sizeof(double) * n, hipMemcpyDeviceToHost, S.stream));
+        return 0;
+    };
+    for (auto &s : S.slabs) {
         const Grid &g = s.g;
+        const i64 t0 = S.remote() ? 0 : g.t0;
         switch (field) {
-            case DOTSOCP_F_PHI:
-                DS_HIP(hipMemcpyAsync(s.phi, host + g.plane * g.t0, sizeof(double) * g.Nphi, hipMemcpyHostToDevice, stream));
-                break;
-            case DOTSOCP_F_C:
-                DS_HIP(hipMemcpyAsync(s.c, host + g.plane * g.t0, sizeof(double) * g.Nphi, hipMemcpyHostToDevice, stream));
-                break;
+            case DOTSOCP_F_PHI: DS_CHECK(cp(s.phi, host + g.plane * t0, g.Nphi)); break;
+            case DOTSOCP_F_C: DS_CHECK(cp(s.c, host + g.plane * t0, g.Nphi)); break;
             case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: {
                 double *d = field == DOTSOCP_F_Q ? s.q : (field == DOTSOCP_F_ALPHA ? s.alpha : s.weight);
-                DS_HIP(hipMemcpyAsync(d, host + g.plane * g.t0, sizeof(double) * g.Nz, hipMemcpyHostToDevice, stream));
-                if (g.bxLayer > 0)
-                    DS_HIP(hipMemcpyAsync(d + g.offBx, host + bxG + g.bxLayer * g.t0, sizeof(double) * g.bxLayer * g.ntl,
-                                          hipMemcpyHostToDevice, stream));
-                if (g.byLayer > 0)
-                    DS_HIP(hipMemcpyAsync(d + g.offBy, host + byG + g.byLayer * g.t0, sizeof(double) * g.byLayer * g.ntl,
-                                          hipMemcpyHostToDevice, stream));
+                DS_CHECK(cp(d, host + g.plane * t0, g.Nz));
+                DS_CHECK(cp(d + g.offBx, host + bxG + g.bxLayer * t0, g.bxLayer * g.ntl));
+                DS_CHECK(cp(d + g.offBy, host + byG + g.byLayer * t0, g.byLayer * g.ntl));
                 break;
             }
             case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
                 double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
-                const int K = prob.dim == 1 ? 6 : 10;
-                if (prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, stream));
+                const int K = S.prob.dim == 1 ? 6 : 10;
+                if (up && S.prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, S.stream));
                 for (int j = 0; j < K; ++j) {
-                    const int pj = prob.dim == 1 ? k1dCols[j] : j;
-                    DS_HIP(hipMemcpyAsync(d + pj * g.Nz, host + j * NzG + g.plane * g.t0, sizeof(double) * g.Nz,
-                                          hipMemcpyHostToDevice, stream));
+                    const int pj = S.prob.dim == 1 ? k1dCols[j] : j;
+                    DS_CHECK(cp(d + pj * g.Nz, host + j * NzG + g.plane * t0, g.Nz));
                 }
                 break;
             }
         }
     }
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_HIP(hipStreamSynchronize(S.stream));
     return 0;
+}
+
+int Solver::upload(int field, const double *host) {
+    DS_ARG(host != nullptr, "host pointer is NULL");
+    DS_ARG(field_len(field) >= 0, "unknown field");
+    DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "weight uploaded to an unweighted problem");
+    if (begun) { set_error("upload() after begin()"); return DOTSOCP_ESTATE; }
+    DS_HIP(hipSetDevice(device));
+    return copy_field(*this, field, const_cast<double *>(host), true);
 }
 
 int Solver::download(int field, double *host) {
     DS_ARG(host != nullptr, "host pointer is NULL");
-    DS_ARG(field_len(field, false) >= 0, "unknown field");
+    DS_ARG(field_len(field) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
     DS_HIP(hipSetDevice(device));
     if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) DS_CHECK(materialise());
-    const i64 NzG = ny * nx * (nt - 1);
-    const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * nt;
-    for (auto &s : slabs) {
-        const Grid &g = s.g;
-        switch (field) {
-            case DOTSOCP_F_PHI:
-                DS_HIP(hipMemcpyAsync(host + g.plane * g.t0, s.phi, sizeof(double) * g.Nphi, hipMemcpyDeviceToHost, stream));
-                break;
-            case DOTSOCP_F_C:
-                DS_HIP(hipMemcpyAsync(host + g.plane * g.t0, s.c, sizeof(double) * g.Nphi, hipMemcpyDeviceToHost, stream));
-                break;
-            case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: {
-                const double *d = field == DOTSOCP_F_Q ? s.q : (field == DOTSOCP_F_ALPHA ? s.alpha : s.weight);
-                DS_HIP(hipMemcpyAsync(host + g.plane * g.t0, d, sizeof(double) * g.Nz, hipMemcpyDeviceToHost, stream));
-                if (g.bxLayer > 0)
-                    DS_HIP(hipMemcpyAsync(host + bxG + g.bxLayer * g.t0, d + g.offBx, sizeof(double) * g.bxLayer * g.ntl,
-                                          hipMemcpyDeviceToHost, stream));
-                if (g.byLayer > 0)
-                    DS_HIP(hipMemcpyAsync(host + byG + g.byLayer * g.t0, d + g.offBy, sizeof(double) * g.byLayer * g.ntl,
-                                          hipMemcpyDeviceToHost, stream));
-                break;
-            }
-            case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
-                const double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
-                const int K = prob.dim == 1 ? 6 : 10;
-                for (int j = 0; j < K; ++j) {
-                    const int pj = prob.dim == 1 ? k1dCols[j] : j;
-                    DS_HIP(hipMemcpyAsync(host + j * NzG + g.plane * g.t0, d + pj * g.Nz, sizeof(double) * g.Nz,
-                                          hipMemcpyDeviceToHost, stream));
-                }
-                break;
-            }
-        }
-    }
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_CHECK(copy_field(*this, field, host, false));
     // after finish(): var.alpha = sigma * alpha, var.beta = sigma * beta  (solver_socp_inPALM.m:335-336)
     if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) {
-        const i64 n = field_len(field, false);
+        const i64 n = field_len(field);
         for (i64 i = 0; i < n; ++i) host[i] = sigma * host[i];
     }
     return 0;
@@ -357,13 +502,16 @@ int Solver::begin(const dotsocp_opts *o) {
     update_coef();
     // alpha /= sigma, beta /= sigma, c /= sigma                                                       // :102-104
     DS_CHECK(scale_state(1.0, sigma, 1.0, true));
+    DS_CHECK(exchange_q_halo());
     sigmaScale = 1.0;
     it = 0;
     stopped = false;
+    deferred = false;
     hist_kkt.clear(); hist_time.clear(); hist_iter.clear(); hist_gap.clear();
     for (int i = 0; i < PH_COUNT; ++i) { phase_ms[i] = 0; phase_launches[i] = 0; }
     begun = true;
     elapsed_prev = 0.0;
+    elapsed_agreed = 0.0;
     t_begin = std::chrono::steady_clock::now();
     return 0;
 }
@@ -371,71 +519,101 @@ int Solver::begin(const dotsocp_opts *o) {
 // --------------------------------------------------------------------------------------
 // the four steps of one iteration
 // --------------------------------------------------------------------------------------
-int Solver::poisson(Slab &s, const double *rhs, double *out) {
-    // phi = idctn(dctn(rhs) ./ kernel), kernel = D^2 * initialize_FFTkernel  (:96,194)
-    const Grid &g = s.g;
-    double *a = s.w0, *b = s.w1;
-    DS_CHECK(launch_dct_axis(py, rhs, b, g.ny, g.nx, g.ntl, 0, 0, stream));
-    DS_CHECK(launch_dct_axis(px, b, a, g.ny, g.nx, g.ntl, 1, 0, stream));
-    if (dct_plan_is_pow2(pt)) {
-        DS_CHECK(launch_dct_t_solve(pt, a, a, g.ny, g.nx, 0, g.nt, D * D, cy, cx, ct, stream));
-    } else {
-        DS_CHECK(launch_dct_axis(pt, a, b, g.ny, g.nx, g.ntl, 2, 0, stream));
-        DS_CHECK(launch_spectral_divide(b, g.ny, g.nx, g.nt, 0, g.nx, D * D, cy, cx, ct, stream));
-        DS_CHECK(launch_dct_axis(pt, b, a, g.ny, g.nx, g.ntl, 2, 1, stream));
+// phi = idctn(dctn(rhs) ./ kernel), kernel = D^2 * initialize_FFTkernel  (:96,194); rhs is in w0
+int Solver::poisson_all() {
+    const i64 plane = ny * nx;
+    const bool tp2 = dct_plan_is_pow2(pt);
+    for (auto &s : slabs) {
+        const Grid &g = s.g;
+        DS_CHECK(launch_dct_axis(py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, stream));
+        DS_CHECK(launch_dct_axis(px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, stream));
     }
-    DS_CHECK(launch_dct_axis(px, a, b, g.ny, g.nx, g.ntl, 1, 1, stream));
-    DS_CHECK(launch_dct_axis(py, b, out, g.ny, g.nx, g.ntl, 0, 1, stream));
+    if (multi()) DS_CHECK(transpose(true));
+    for (auto &s : slabs) {
+        double *p = multi() ? s.pencil : s.w0;
+        double *p2 = multi() ? s.pencil2 : s.w1;
+        if (tp2) {
+            DS_CHECK(launch_dct_t_solve(pt, p, p, ny, plane, s.l0, s.nl, nt, D * D, cy, cx, ct, stream));
+        } else {
+            DS_CHECK(launch_dct_axis(pt, p, p2, s.nl, 1, nt, 2, 0, stream));
+            DS_CHECK(launch_spectral_divide_pencil(p2, ny, plane, s.l0, s.nl, nt, D * D, cy, cx, ct, stream));
+            DS_CHECK(launch_dct_axis(pt, p2, p, s.nl, 1, nt, 2, 1, stream));
+        }
+    }
+    if (multi()) DS_CHECK(transpose(false));
+    for (auto &s : slabs) {
+        const Grid &g = s.g;
+        DS_CHECK(launch_dct_axis(px, s.w0, s.w1, g.ny, g.nx, g.ntl, 1, 1, stream));
+        DS_CHECK(launch_dct_axis(py, s.w1, s.phi, g.ny, g.nx, g.ntl, 0, 1, stream));
+    }
     return 0;
 }
 
 int Solver::phase_phi() {
-    for (auto &s : slabs) {
-        prof_begin(PH_RHS);
-        DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, stream));
-        prof_end(PH_RHS);
-        prof_begin(PH_POISSON);
-        DS_CHECK(poisson(s, s.w0, s.phi));
-        prof_end(PH_POISSON);
+    const i64 plane = ny * nx;
+    if (multi()) {
+        prof_begin(PH_COMM);
+        for (auto &s : slabs)
+            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q, s.alpha, s.weight, s.send_plane, stream));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, plane));
+        prof_end(PH_COMM);
+    }
+    prof_begin(PH_RHS);
+    for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, stream));
+    prof_end(PH_RHS);
+    prof_begin(PH_POISSON);
+    DS_CHECK(poisson_all());
+    prof_end(PH_POISSON);
+    if (multi()) {
+        prof_begin(PH_COMM);
+        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, plane));
+        prof_end(PH_COMM);
     }
     return 0;
 }
 
 int Solver::phase_z() {
+    if (!fused) {
+        prof_begin(PH_PROJ);
+        for (auto &s : slabs) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, stream));
+        prof_end(PH_PROJ);
+        return 0;
+    }
+    const int ph = deferred ? PH_FUSED_B : PH_FUSED_A;
+    prof_begin(ph);
     for (auto &s : slabs) {
-        if (!fused) {
-            prof_begin(PH_PROJ);
-            DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, stream));
-            prof_end(PH_PROJ);
-            continue;
-        }
         FusedArgs a{};
         a.q = s.q;
         a.q2 = s.q2;
         a.sx = s.sx;
         a.sy = s.sy;
+        a.beta_in = s.beta;
         if (deferred) {
             // beta^k = beta^{k-1} + tau (z^k - BF q^k - d) folded into this iteration's projection
             a.q_old = s.q_old;
-            a.beta_in = s.beta;
             a.beta_out = s.beta2;
-            prof_begin(PH_FUSED_B);
             DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, stream));
-            prof_end(PH_FUSED_B);
             std::swap(s.beta, s.beta2);
         } else {
-            a.beta_in = s.beta;
-            prof_begin(PH_FUSED_A);
             DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, stream));
-            prof_end(PH_FUSED_A);
         }
+    }
+    prof_end(ph);
+    if (multi()) {
+        // adjoint sums of every slab's last cell for the first edge layer of its right neighbour
+        prof_begin(PH_COMM);
+        for (auto &s : slabs)
+            if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.q2, s.sx, s.sy, s.send_bx, s.send_by, stream));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_bx; }, [](Slab &s) { return s.tail_bx; }, slabs[0].g.bxLayer));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.tail_by; }, slabs[0].g.byLayer));
+        prof_end(PH_COMM);
     }
     return 0;
 }
 
 int Solver::phase_q() {
+    prof_begin(PH_QSTEP);
     for (auto &s : slabs) {
-        prof_begin(PH_QSTEP);
         if (!fused) {
             DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
         } else {
@@ -444,8 +622,9 @@ int Solver::phase_q() {
                                         s.alpha, stream));
             std::swap(s.q, s.q_old);
         }
-        prof_end(PH_QSTEP);
     }
+    prof_end(PH_QSTEP);
+    DS_CHECK(exchange_q_halo());
     return 0;
 }
 
@@ -454,11 +633,9 @@ int Solver::phase_mult() {
         deferred = true;     // the multiplier step is executed by the next fused pass (or by materialise())
         return 0;
     }
-    for (auto &s : slabs) {
-        prof_begin(PH_BETA);
-        DS_CHECK(launch_beta_update(s.g, lc, s.q, s.z, s.beta, stream));
-        prof_end(PH_BETA);
-    }
+    prof_begin(PH_BETA);
+    for (auto &s : slabs) DS_CHECK(launch_beta_update(s.g, lc, s.q, s.z, s.beta, stream));
+    prof_end(PH_BETA);
     return 0;
 }
 
@@ -466,6 +643,7 @@ int Solver::phase_mult() {
 // 212-215) so that beta, z are the iterates the KKT block, the rescale block and the outputs see.
 int Solver::materialise() {
     if (!fused || !deferred) return 0;
+    prof_begin(PH_MATERIALISE);
     for (auto &s : slabs) {
         FusedArgs a{};
         a.q_old = s.q_old;
@@ -473,10 +651,9 @@ int Solver::materialise() {
         a.beta_in = s.beta;
         a.beta_out = s.beta;
         a.z_out = s.z;
-        prof_begin(PH_MATERIALISE);
         DS_CHECK(launch_cone_fused(2, s.g, lc, s.fg, a, stream));
-        prof_end(PH_MATERIALISE);
     }
+    prof_end(PH_MATERIALISE);
     deferred = false;
     return 0;
 }
@@ -487,14 +664,40 @@ int Solver::kkt_sums(double *S) {
     k.kappa = sigma * cScale * D;
     k.dsD = dScale / D;
     k.dsE = dScale / E;
-    for (int i = 0; i < S_COUNT; ++i) S[i] = 0.0;
+    if (multi()) {
+        const i64 plane = ny * nx;
+        for (auto &s : slabs)
+            if (!s.g.last)
+                DS_CHECK(launch_kkt_tail(s.g, s.alpha, s.beta, s.weight, s.send_plane, s.send_plane2, s.send_bx, s.send_by,
+                                         stream));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.a0_prev; }, plane));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane2; }, [](Slab &s) { return s.a0w_prev; }, plane));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_bx; }, [](Slab &s) { return s.btail_bx; }, slabs[0].g.bxLayer));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.btail_by; }, slabs[0].g.byLayer));
+    }
+    for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
     for (auto &s : slabs) {
         KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
         DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, stream));
+        if (remote()) break;
         DS_HIP(hipMemcpyAsync(h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
         DS_HIP(hipStreamSynchronize(stream));
         for (int i = 0; i < S_COUNT; ++i) S[i] += h_sums[i];
     }
+    S[S_COUNT] = elapsed();
+    if (remote()) {
+        // sum the partial sums over the ranks; slot S_COUNT carries the wall clock (max via a second reduce)
+        Rccl &api = rccl_api();
+        Slab &s = slabs[0];
+        DS_NCCL(api.AllReduce(s.kw.sums, d_red, S_COUNT, ncclDouble, ncclSum, (ncclComm_t)nccl, stream));
+        h_sums[S_COUNT] = S[S_COUNT];
+        DS_HIP(hipMemcpyAsync(d_red + S_COUNT, h_sums + S_COUNT, sizeof(double), hipMemcpyHostToDevice, stream));
+        DS_NCCL(api.AllReduce(d_red + S_COUNT, d_red + S_COUNT, 1, ncclDouble, ncclMax, (ncclComm_t)nccl, stream));
+        DS_HIP(hipMemcpyAsync(h_sums, d_red, sizeof(double) * (S_COUNT + 1), hipMemcpyDeviceToHost, stream));
+        DS_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i <= S_COUNT; ++i) S[i] = h_sums[i];
+    }
+    elapsed_agreed = S[S_COUNT];
     return 0;
 }
 
@@ -503,7 +706,7 @@ int Solver::rescale_block() {
     bool scaleYes = false;
     double normPhis = 0, normAlps = 0;
     auto norms = [&](double &nPhis, double &nAlps) -> int {
-        double S[S_COUNT];
+        double S[S_COUNT + 1];
         DS_CHECK(materialise());
         DS_CHECK(kkt_sums(S));
         const double sh = sqrt(h);
@@ -572,11 +775,14 @@ static void adjust_lagrangian_param(double &sigma, double xi, double &factor) { 
 
 // solver_socp_inPALM.m:222-323
 int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
-    double S[S_COUNT];
+    double S[S_COUNT + 1];
     DS_CHECK(materialise());
     prof_begin(PH_KKT);
     DS_CHECK(kkt_sums(S));
     prof_end(PH_KKT);
+    // one slab per process: the ranks must take the time-limit decision together, so it is taken
+    // here from the maximum of their wall clocks (time-outs are detected at KKT checks only)
+    if (remote()) timed_out = elapsed_agreed > time_limit;
     const double sh = sqrt(h);
     auto nrm = [&](int i) { return sh * sqrt(S[i]); };
     const double norm_q = nrm(S_Q2), norm_z = nrm(S_Z2), norm_Aphi = nrm(S_APHI2);
@@ -606,7 +812,7 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
     const double dualVal = (sigma * cScale * dScale * h) * S[S_CPHI];
     const double pdGap = fabs(priVal - dualVal) / (1 + fabs(priVal) + fabs(dualVal));
     for (int i = 0; i < 7; ++i) hist_kkt.push_back(org[i]);
-    hist_time.push_back(elapsed());
+    hist_time.push_back(remote() ? elapsed_agreed : elapsed());
     hist_iter.push_back((double)it);
     hist_gap.push_back(pdGap);
     // stop criterion (:287-290); stopCondition = [1,3,6,7] or [1,3,6] (:117-121)
@@ -643,7 +849,8 @@ int Solver::step(bool *brk) {
     DS_CHECK(phase_q());
     DS_CHECK(phase_mult());
     const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
-    const bool timed_out = elapsed() > time_limit;
+    // with one slab per process a per-rank clock could split the ranks: see kkt_block()
+    const bool timed_out = remote() ? false : (elapsed() > time_limit);
     if (opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out)        // :221
         DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
     return 0;

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             tmp += c.ax * phi[node + g.ny];
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
-            if (tl == 0 && !g.first) q2 += c.sf * tail_bx[y + g.ny * x];
+            if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];      // left slab's part, already times sf
             q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
         } else {
             if (y >= g.ny - 1 || x >= g.nx) return;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             tmp += c.ay * phi[node + 1];
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
-            if (tl == 0 && !g.first) q2 += c.sf * tail_by[y + (g.ny - 1) * x];
+            if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
             q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
         }
     }
@@ -250,6 +250,74 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *tail_by, double *q_out, double *alpha, hipStream_t st) {
     return weight ? launch_qstep_fused_t<true>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st)
                   : launch_qstep_fused_t<false>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st);
+}
+
+// Time-slab mode: the fused cone kernel leaves, in the halo layer (index ncl) of q2 and of the side
+// buffers, the adjoint sums that the LAST owned cell contributes to the first edge layer of the
+// right neighbour.  This kernel completes them (tile-boundary edges) into two contiguous planes.
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_tail_finalize(Grid g, LoopCoef c, FusedGeom fg,
+                                                                   const double *__restrict__ q2v,
+                                                                   const double *__restrict__ sx,
+                                                                   const double *__restrict__ sy,
+                                                                   double *__restrict__ tail_bx,
+                                                                   double *__restrict__ tail_by) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    const i64 tl = g.ncl;
+    if (y < g.ny && x < g.nx - 1) {
+        double v = q2v[g.offBx + g.bxLayer * tl + y + g.ny * x];
+        if ((x % fg.XB) == fg.XB - 1) v = c.sf * (v + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
+        tail_bx[y + g.ny * x] = v;
+    }
+    if (y < g.ny - 1 && x < g.nx) {
+        double v = q2v[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x];
+        if ((y & 63) == 63) v = c.sf * (v + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
+        tail_by[y + (g.ny - 1) * x] = v;
+    }
+}
+
+int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,
+                         const double *sy, double *tail_bx, double *tail_by, hipStream_t st) {
+    hipLaunchKernelGGL(k_tail_finalize, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c, fg, q2, sx, sy, tail_bx,
+                       tail_by);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// Time-slab mode, KKT block: what the right neighbour needs from this slab's LAST cell layer --
+// alpha0, w.*alpha0 and the raw partial adjoint sums of beta (cone columns 4,5 / 8,9).
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_tail(Grid g, const double *__restrict__ alpha,
+                                                              const double *__restrict__ beta,
+                                                              const double *__restrict__ weight,
+                                                              double *__restrict__ a0, double *__restrict__ a0w,
+                                                              double *__restrict__ bt_bx, double *__restrict__ bt_by) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    const i64 tl = g.ncl - 1;
+    if (y < g.ny && x < g.nx) {
+        const i64 cidx = y + g.ny * (x + g.nx * tl);
+        const double a = alpha[cidx];
+        a0[y + g.ny * x] = a;
+        a0w[y + g.ny * x] = weight ? weight[cidx] * a : a;
+    }
+    if (y < g.ny && x < g.nx - 1) {
+        double acc = beta[3 * g.Nz + y + g.ny * ((x + 1) + g.nx * tl)];
+        acc += beta[4 * g.Nz + y + g.ny * (x + g.nx * tl)];
+        bt_bx[y + g.ny * x] = acc;
+    }
+    if (y < g.ny - 1 && x < g.nx) {
+        double acc = beta[7 * g.Nz + (y + 1) + g.ny * (x + g.nx * tl)];
+        acc += beta[8 * g.Nz + y + g.ny * (x + g.nx * tl)];
+        bt_by[y + (g.ny - 1) * x] = acc;
+    }
+}
+
+int launch_kkt_tail(const Grid &g, const double *alpha, const double *beta, const double *weight, double *a0,
+                    double *a0w, double *bt_bx, double *bt_by, hipStream_t st) {
+    hipLaunchKernelGGL(k_kkt_tail, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, alpha, beta, weight, a0, a0w, bt_bx,
+                       bt_by);
+    DS_HIP(hipGetLastError());
+    return 0;
 }
 
 // x = x * mul / div  (left to right, like `alpha * dScale2 / cScale2^2`, solver_socp_inPALM.m:170-178,312-314)

@@ -72,10 +72,50 @@ def initialize(rho0, rho1, nt, lazy_zeros=False):
     return var, model
 
 
+def initialize_slab(rho0, rho1, nt, t0, t1):
+    """The time slab [t0, t1) of what initialize(rho0, rho1, nt) returns (cold start: q, alpha, z,
+    beta stay on the device as zeros), for the one-process-per-GPU mode: var.phi and model.c hold
+    only the slab's nodes; model.nt stays global; model.n_global / model.c_sumsq carry what
+    InitialScaling needs from the full arrays (initialize.m:42-50)."""
+    rho0 = np.asarray(rho0, dtype=np.float64)
+    rho1 = np.asarray(rho1, dtype=np.float64)
+    var, model = VarHandle(), ModelHandle()
+    model.rho0, model.rho1 = rho0, rho1
+    ht = 1.0 / (nt - 1)
+    ntl = t1 - t0
+    if rho0.ndim == 2:
+        ny, nx = rho0.shape
+        model.nx, model.ny, model.nt = nx, ny, nt
+        xx, yy = np.meshgrid(np.arange(nx) * (1.0 / (nx - 1)), np.arange(ny) * (1.0 / (ny - 1)))
+        prof = (0.5 * (xx ** 2 + yy ** 2)).ravel(order="F")
+        plane = nx * ny
+        r0, r1 = rho0.ravel(order="F"), rho1.ravel(order="F")
+    else:
+        nx = rho0.size
+        model.nx, model.nt = nx, nt
+        prof = 0.5 * (np.arange(nx) * (1.0 / (nx - 1))) ** 2
+        plane = nx
+        r0, r1 = rho0.ravel(), rho1.ravel()
+    var.phi = np.tile(prof, ntl)
+    model.c = np.zeros(plane * ntl)
+    c0, c1 = -r0 / ht, r1 / ht
+    if t0 == 0:
+        model.c[:plane] = c0
+    if t1 == nt:
+        model.c[plane * (ntl - 1):] = c1
+    model.n_global = plane * nt
+    model.c_sumsq = float(np.dot(c0, c0) + np.dot(c1, c1))
+    model.slab = (t0, t1)
+    var.z = var.beta = var.q = var.alpha = None
+    var.qInd = None
+    model.grad = None
+    return var, model
+
+
 def InitialScaling(var, model, scalingYes, lastLevelKKT=None, dim=2, weighted=False):
     """socp/dot2d/solver_dotsocp2d.m:304-365; 1-D: solver_dotsocp1d.m:263-300 (hMean = h^(1/2));
     weighted: solver_wdotsocp2d.m:297-343 (`adjust`, E2 safeguard 4)."""
-    h = 1.0 / var.phi.size
+    h = 1.0 / getattr(model, "n_global", var.phi.size)
     hMean = h ** (1.0 / 3.0) if dim == 2 else h ** 0.5
     if lastLevelKKT is None or not hasattr(var, "E2"):
         Escale2 = np.sqrt(2.0)
@@ -88,8 +128,12 @@ def InitialScaling(var, model, scalingYes, lastLevelKKT=None, dim=2, weighted=Fa
             Escale2 = var.E2 * max(1 / np.sqrt(2.0), ratio / lowerRatio)
         else:
             Escale2 = var.E2 * min(np.sqrt(2.0), max(1.0, ratio))
+    def _norm_c():
+        # slab mode: ||c|| of the full vector from its two non-zero layers
+        return np.sqrt(h) * np.sqrt(model.c_sumsq) if hasattr(model, "c_sumsq") else normL2(model.c, h)
+
     if scalingYes:
-        norm_c = normL2(model.c, h) * np.sqrt(model.nt)
+        norm_c = _norm_c() * np.sqrt(model.nt)
         norm_d = np.sqrt(2.0)
         adjust = 10.0 ** np.mean(np.log10(model.weight + 1e-10)) if weighted else 1.0
         D = np.sqrt(2.0) * np.sqrt(hMean) * adjust
@@ -107,7 +151,7 @@ def InitialScaling(var, model, scalingYes, lastLevelKKT=None, dim=2, weighted=Fa
             var.beta = (1.0 / cScale / E) * var.beta
     else:
         cScale = dScale = D = E = 1.0
-        model.normc = normL2(model.c, h)
+        model.normc = _norm_c()
         model.normd = np.sqrt(2.0)
     var.cScale, var.dScale, var.D, var.E, var.E2 = cScale, dScale, D, E, Escale2
 

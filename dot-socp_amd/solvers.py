@@ -36,7 +36,9 @@ def _has(opts, name):
 class InPALMContext:
     """Stateful handle on one device-resident loop (create -> upload -> begin -> run* -> finish)."""
 
-    def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False):
+    def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False, rccl=None):
+        """rccl = (unique_id_bytes, rank, world): one process per GPU, this process owns time slab
+        `rank`; var / model then hold the LOCAL slab of every field (model.nt stays the global nt)."""
         L = capi.lib()
         one_d = not hasattr(model, "ny")
         p = capi.Problem()
@@ -51,6 +53,10 @@ class InPALMContext:
         if not self._ctx:
             raise capi.DotsocpError(-1, L.dotsocp_last_error().decode())
         try:
+            if rccl is not None:
+                uid, rk, wd = rccl
+                buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(uid))
+                capi.check(L.dotsocp_attach_rccl(self._ctx, buf, int(rk), int(wd)))
             # a field left as None keeps the device default (zeros), e.g. z, beta, q, alpha of a cold start
             for f, a in ((capi.F_PHI, var.phi), (capi.F_Q, var.q), (capi.F_ALPHA, var.alpha),
                          (capi.F_Z, var.z), (capi.F_BETA, var.beta), (capi.F_C, model.c)):
@@ -129,9 +135,10 @@ class InPALMContext:
         self.close()
 
 
-def solver_socp_inPALM(var, opts, model, device=0):
-    """[runHist, sigma] = solver_socp_inPALM(var, opts, model); `var` is mutated in place."""
-    ctx = InPALMContext(var, opts, model, weighted=False, device=device)
+def solver_socp_inPALM(var, opts, model, device=0, nslabs=1):
+    """[runHist, sigma] = solver_socp_inPALM(var, opts, model); `var` is mutated in place.
+    nslabs > 1 runs the multi-GPU time-slab algorithm with all slabs on this one device."""
+    ctx = InPALMContext(var, opts, model, weighted=False, device=device, nslabs=nslabs)
     try:
         ctx.run(-1)
         return ctx.finish()
@@ -139,9 +146,9 @@ def solver_socp_inPALM(var, opts, model, device=0):
         ctx.close()
 
 
-def solver_wsocp_inPALM(var, opts, model, device=0):
+def solver_wsocp_inPALM(var, opts, model, device=0, nslabs=1):
     """[runHist, sigma] = solver_wsocp_inPALM(var, opts, model) (model.weight required)."""
-    ctx = InPALMContext(var, opts, model, weighted=True, device=device)
+    ctx = InPALMContext(var, opts, model, weighted=True, device=device, nslabs=nslabs)
     try:
         ctx.run(-1)
         return ctx.finish()

@@ -135,3 +135,75 @@ def test_run_in_pieces_is_identical():
         res.append((var.phi.copy(), var.beta.copy(), sigma, hist["kkt"].copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and np.array_equal(res[0][3], res[1][3])
+
+
+# --------------------------------------------------------------------------------------------------
+# time slabs: the multi-GPU algorithm (halo exchange + slab<->pencil transposes of the Poisson solve)
+# executed with all slabs on the one GPU of the test box must reproduce the single-slab run
+# --------------------------------------------------------------------------------------------------
+def _run_slabs(rho0, rho1, nt, opts, nslabs, weight=None):
+    var, model, o = _gpu_level(rho0, rho1, nt, opts, "inPALM", weight)
+    solve = D.solver_wsocp_inPALM if weight is not None else D.solver_socp_inPALM
+    hist, sigma = solve(var, o, model, nslabs=nslabs)
+    return var, hist, sigma
+
+
+@pytest.mark.parametrize("case", ["dot2d_32x32x16", "dot2d_24x40x12", "dot2d_33x33x17", "dot1d_128x32", "wdot2d_32x32x16"])
+@pytest.mark.parametrize("nslabs", [2, 3, 4])
+def test_time_slabs_match_single_slab(case, nslabs, request):
+    if "unfused" in request.node.name:
+        pytest.skip("time slabs exist on the fused dataflow only")
+    weight = None
+    if case == "dot1d_128x32":
+        rho0, rho1 = get_example_1d("gaussian", 128)
+        nt = 32
+    else:
+        a, b, nt = [int(v) for v in case.split("_")[1].split("x")]
+        rho0, rho1 = get_example_2d("example1", a, b)
+        if case.startswith("wdot2d"):
+            barrier = gene_barrier_of_circle_pillar()
+            weight = get_weight_by_barrier(b, a, nt, barrier)
+            rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    opts = dict(tol=0.0, maxit=30)
+    ref, h1, s1 = _run_slabs(rho0, rho1, nt, opts, 1, weight)
+    got, hn, sn = _run_slabs(rho0, rho1, nt, opts, nslabs, weight)
+    np.testing.assert_array_equal(hn["iter"], h1["iter"])
+    np.testing.assert_allclose(hn["kkt"], h1["kkt"], rtol=1e-7, atol=1e-10)
+    assert abs(sn - s1) <= 1e-12 * s1
+    # only summation orders differ (tile-boundary partial sums, per-slab norm partials)
+    errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
+    assert max(errs.values()) <= (1e-8 if weight is not None else 1e-10), errs
+
+
+def test_time_slabs_free_running_against_oracle(request):
+    if "unfused" in request.node.name:
+        pytest.skip("time slabs exist on the fused dataflow only")
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    ovar, omodel, o_hist, o_sigma = OD.solve_single_level(rho0, rho1, 16, dict(tol=1e-4))
+    var, hist, sigma = _run_slabs(rho0, rho1, 16, dict(tol=1e-4), 4)
+    assert hist["iter"][-1] == o_hist["iter"][-1]
+    D.recoverOrgVar(var)
+    errs = {f: _relerr(getattr(var, f), getattr(ovar, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-7, errs
+
+
+def test_rccl_communicator_world1(request):
+    """One-process-per-GPU mode with a world of one rank: exercises the RCCL binding (dlopen,
+    ncclCommInitRank, the all-reduce of the KKT sums) on the single GPU of the test box; the
+    neighbour exchanges of larger worlds are the ones the in-process slab tests validate."""
+    if "unfused" in request.node.name:
+        pytest.skip("time slabs exist on the fused dataflow only")
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    ref, h1, s1 = _run_slabs(rho0, rho1, 16, dict(tol=0.0, maxit=25), 1)
+    var, model = D.initialize_slab(rho0, rho1, 16, 0, 16)
+    o = OD.default_opts(dict(tol=0.0, maxit=25), "inPALM", False)
+    D.InitialScaling(var, model, True, None, dim=2)
+    assert var.D == ref.D and abs(var.cScale - D.initialize(rho0, rho1, 16)[0].phi.size * 0 - var.cScale) == 0
+    ctx = D.InPALMContext(var, o, model, rccl=(D.capi.rccl_unique_id(), 0, 1))
+    ctx.run(-1)
+    hist, sigma = ctx.finish(download=False)
+    phi = ctx.download(D.capi.F_PHI, var.phi)
+    ctx.close()
+    np.testing.assert_array_equal(hist["iter"], h1["iter"])
+    np.testing.assert_allclose(hist["kkt"], h1["kkt"], rtol=1e-9, atol=1e-12)
+    assert _relerr(phi, ref.phi) <= 1e-11
