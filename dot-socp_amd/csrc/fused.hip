@@ -8,7 +8,8 @@
 //     q2       = F* B* (z^{k+1} + beta^k)              adjoint gather for the q-step        (:205)
 //   traffic: beta in + beta out + q_old + q + q2 = 8 (20 Nz + 3 Nq) bytes.
 //   MODE_A: same without the deferred update (beta already current): 8 (10 Nz + 2 Nq) bytes.
-//   MODE_M: materialise -- beta update + write z (needed by the KKT block / rescale / outputs).
+//   MODE_M (2): materialise -- beta update + write z (needed by the rescale block / outputs).
+//   MODE_Z (3): z = Pi_Q(BF q_old + d - beta_in) only (z of the last iteration from the kept beta^k).
 //   (line numbers: socp/dot2d/algorithms/solver_socp_inPALM.m)
 //
 // Mapping: a workgroup owns a 64 (y) x XB (x) tile of cell columns and MARCHES through a chunk
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
     const i64 t0 = (i64)blockIdx.z * a.TC;
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
     const bool lastChunk = (t1 == g.ncl);
-    const i64 tstart = (MODE != 2 && t0 > 0) ? t0 - 1 : t0;
+    const i64 tstart = (MODE < 2 && t0 > 0) ? t0 - 1 : t0;
     const i64 nxblk = gridDim.y, nyblk = gridDim.x;
 
     EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo;
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
     double p3 = 0.0, p4 = 0.0, p7 = 0.0, p8 = 0.0;     // "t+1" cone entries of the previous cell
     int par = 0;
     // one extra virtual step (tl == ncl, no cell) on the last chunk emits the final edge layer
-    const i64 tstop = (MODE != 2 && lastChunk) ? t1 + 1 : t1;
+    const i64 tstop = (MODE < 2 && lastChunk) ? t1 + 1 : t1;
     for (i64 tl = tstart; tl < tstop; ++tl) {
         const bool hasCell = tl < g.ncl;
         const bool own = tl >= t0;                      // false only for the recomputed cell in front of the chunk
@@ -69,9 +70,11 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
                     b[j] = b[j] + c.tau * r;
                 }
                 if (own && inb) {
+                    if (MODE != 3) {
 #pragma unroll
-                    for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
-                    if (MODE == 2) {
+                        for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
+                    }
+                    if (MODE >= 2) {
 #pragma unroll
                         for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zo[j];
                     }
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
                 curo = nxto;
             }
             cur = nxt;
-            if (MODE != 2) {
+            if (MODE < 2) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) v[j] = v[j] - b[j];
                 proj_row<10>(v);
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 #pragma unroll
             for (int j = 0; j < 10; ++j) w[j] = 0.0;
         }
-        if (MODE != 2) {
+        if (MODE < 2) {
             // ---- adjoint gather for edge layer tl: ((w1(x+1) + w2(x)) + w3'(x+1)) + w4'(x), ' = previous cell
             xch[par][xl][lane] = make_double2(w[1], p3);
             __syncthreads();
@@ -160,6 +163,7 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
         case 0: hipLaunchKernelGGL((k_cone_fused<0, 4>), grid, blk, 0, st, g, c, a); break;
         case 1: hipLaunchKernelGGL((k_cone_fused<1, 4>), grid, blk, 0, st, g, c, a); break;
         case 2: hipLaunchKernelGGL((k_cone_fused<2, 4>), grid, blk, 0, st, g, c, a); break;
+        case 3: hipLaunchKernelGGL((k_cone_fused<3, 4>), grid, blk, 0, st, g, c, a); break;
         default: set_error("bad fused mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());

@@ -63,7 +63,8 @@ struct FusedArgs {
     i64 TC;
 };
 int fused_geometry(const Grid &g, FusedGeom &fg);
-// mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z
+// mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z;
+// 3: z only, from (q_old, beta_in)
 int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
                       hipStream_t st);
 
@@ -104,9 +105,15 @@ struct KktHalo {
     const double *a0_prev, *a0w_prev, *btail_bx, *btail_by;
 };
 i64 kkt_partials_needed(const Grid &g);
+// parts: bit mask of 1 node, 2 cell (+ q0 entries; needs a stored z), 4 bx edges, 8 by edges
 int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double *phi, const double *q,
                const double *alpha, const double *z, const double *beta, const double *cvec,
-               const double *weight, const KktHalo &halo, const KktWork &w, hipStream_t st);
+               const double *weight, const KktHalo &halo, const KktWork &w, int parts, hipStream_t st);
+// fused path: pending multiplier step (beta_in -> beta_out, distinct buffers) + the cell part of the sums
+int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, FusedArgs a,
+                            const double *phi, const double *alpha, const double *weight, const KktWork &w,
+                            hipStream_t st);
+int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st);
 
 // ---------------- dct.hip ----------------
 struct DctPlan;   // twiddles / dense matrices for one axis length

@@ -78,6 +78,9 @@ struct Solver {
     bool profiling = false;
     bool fused = true;       // DOTSOCP_FUSED=0 selects the unfused reference dataflow (z stored, 3 cone passes)
     bool deferred = false;   // fused path: beta still holds beta^{k-1}; z is not materialised
+    bool z_valid = true;     // s.z holds the z of the last completed iteration
+    bool z_prev_ok = false;  // s.beta2 / s.q_old still hold (beta^k, q^k): z can be regenerated (MODE_Z)
+    int ensure_z();
     struct Pending { hipEvent_t a, b; int phase; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;

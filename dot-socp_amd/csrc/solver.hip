@@ -170,7 +170,7 @@ int Solver::alloc_slabs(int first, int count) {
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, stream));
         }
         s.kw.maxBlocks = kkt_partials_needed(g);
-        DS_CHECK(dmalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT));
+        DS_CHECK(dzalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT, stream));
         DS_CHECK(dmalloc(&s.kw.sums, S_COUNT));
         pencil_range(plane, world, s.index, &s.l0, &s.nl);
         s.nl -= s.l0;
@@ -393,7 +393,7 @@ int Solver::download(int field, double *host) {
     DS_ARG(field_len(field) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
     DS_HIP(hipSetDevice(device));
-    if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) DS_CHECK(materialise());
+    if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) DS_CHECK(ensure_z());
     DS_CHECK(copy_field(*this, field, host, false));
     // after finish(): var.alpha = sigma * alpha, var.beta = sigma * beta  (solver_socp_inPALM.m:335-336)
     if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) {
@@ -507,6 +507,8 @@ int Solver::begin(const dotsocp_opts *o) {
     it = 0;
     stopped = false;
     deferred = false;
+    z_valid = true;
+    z_prev_ok = false;
     hist_kkt.clear(); hist_time.clear(); hist_iter.clear(); hist_gap.clear();
     for (int i = 0; i < PH_COUNT; ++i) { phase_ms[i] = 0; phase_launches[i] = 0; }
     begun = true;
@@ -580,6 +582,8 @@ int Solver::phase_z() {
         return 0;
     }
     const int ph = deferred ? PH_FUSED_B : PH_FUSED_A;
+    z_valid = false;          // the fused pass forms z^{k+1} in registers only
+    z_prev_ok = false;        // ... and (mode B) overwrites the kept beta^{k-1}
     prof_begin(ph);
     for (auto &s : slabs) {
         FusedArgs a{};
@@ -655,6 +659,29 @@ int Solver::materialise() {
     }
     prof_end(PH_MATERIALISE);
     deferred = false;
+    z_valid = true;
+    return 0;
+}
+
+// z of the last completed iteration in s.z (outputs, rescale block, unfused-style cell sums)
+int Solver::ensure_z() {
+    if (!fused || z_valid) return 0;
+    if (deferred) return materialise();
+    if (!z_prev_ok) {
+        set_error("internal: z cannot be regenerated");
+        return DOTSOCP_ESTATE;
+    }
+    prof_begin(PH_MATERIALISE);
+    for (auto &s : slabs) {
+        FusedArgs a{};
+        a.q_old = s.q_old;
+        a.q = s.q;
+        a.beta_in = s.beta2;      // beta^k, kept by the KKT pass
+        a.z_out = s.z;
+        DS_CHECK(launch_cone_fused(3, s.g, lc, s.fg, a, stream));
+    }
+    prof_end(PH_MATERIALISE);
+    z_valid = true;
     return 0;
 }
 
@@ -664,6 +691,30 @@ int Solver::kkt_sums(double *S) {
     k.kappa = sigma * cScale * D;
     k.dsD = dScale / D;
     k.dsE = dScale / E;
+    // the launches below write per-workgroup partial sums into four regions; grids of different
+    // shapes may use a region on different calls, so stale entries are cleared first
+    for (auto &s : slabs)
+        DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, stream));
+    // ---- cell part (region 1 of the partial sums) ----
+    int rest = 1 | 4 | 8;
+    if (fused && deferred) {
+        // pending multiplier step + cell sums in one pass; beta^k stays in beta2 so that z can be regenerated
+        for (auto &s : slabs) {
+            FusedArgs a{};
+            a.q_old = s.q_old;
+            a.q = s.q;
+            a.beta_in = s.beta;
+            a.beta_out = s.beta2;
+            DS_CHECK(launch_kkt_cells_update(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, stream));
+            std::swap(s.beta, s.beta2);
+        }
+        deferred = false;
+        z_valid = false;
+        z_prev_ok = true;
+    } else {
+        DS_CHECK(ensure_z());
+        rest |= 2;
+    }
     if (multi()) {
         const i64 plane = ny * nx;
         for (auto &s : slabs)
@@ -678,7 +729,8 @@ int Solver::kkt_sums(double *S) {
     for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
     for (auto &s : slabs) {
         KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
-        DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, stream));
+        DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, stream));
+        DS_CHECK(launch_kkt_final(s.g, s.kw, stream));
         if (remote()) break;
         DS_HIP(hipMemcpyAsync(h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
         DS_HIP(hipStreamSynchronize(stream));
@@ -708,6 +760,7 @@ int Solver::rescale_block() {
     auto norms = [&](double &nPhis, double &nAlps) -> int {
         double S[S_COUNT + 1];
         DS_CHECK(materialise());
+        DS_CHECK(ensure_z());
         DS_CHECK(kkt_sums(S));
         const double sh = sqrt(h);
         const double normPhi = sh * sqrt(S[S_PHI2]), normQ = sh * sqrt(S[S_Q2]), normZ = sh * sqrt(S[S_Z2]);
@@ -776,7 +829,6 @@ static void adjust_lagrangian_param(double &sigma, double xi, double &factor) { 
 // solver_socp_inPALM.m:222-323
 int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
     double S[S_COUNT + 1];
-    DS_CHECK(materialise());
     prof_begin(PH_KKT);
     DS_CHECK(kkt_sums(S));
     prof_end(PH_KKT);
@@ -876,7 +928,7 @@ int Solver::run(i64 n_iters, i64 *done) {
 int Solver::finish(dotsocp_result *res) {
     if (!begun) { set_error("finish() before begin()"); return DOTSOCP_ESTATE; }
     DS_HIP(hipSetDevice(device));
-    DS_CHECK(materialise());
+    DS_CHECK(ensure_z());
     DS_HIP(hipStreamSynchronize(stream));
     DS_CHECK(prof_flush());
     finished = true;
