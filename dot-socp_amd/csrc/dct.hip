@@ -106,6 +106,7 @@ __device__ __forceinline__ int bitrev(int k, int lg) { return (int)(__brev((unsi
 
 #define DCT_THREADS 256
 #define DCT_WAVES 4
+#define DCT_BATCH 8   // global loads in flight per lane before the first dependent LDS write
 // LDS rows are padded by one complex element every 16 (stride-16 accesses of the grouped FFT
 // stages and the bit-reversed reads then spread over the banks instead of piling onto one).
 __device__ __host__ __forceinline__ int padi(int p) { return p + (p >> 4); }
@@ -259,20 +260,33 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_axis0(const double *__restr
     double2 *rows = lds + (wave << lrw) * rowStride;
     const i64 pair0 = ((i64)blockIdx.x * DCT_WAVES + wave) << lrw;      // first pair of lines of this wave
     const int total = 1 << (lrw + lh);                                    // (row, j) with j = k / 2
-    // ---- load: two consecutive elements of both lines per lane ----
-    for (int b = lane; b < total; b += 64) {
-        const int rr = b >> lh, j = b & ((1 << lh) - 1);
-        const i64 La = 2 * (pair0 + rr);
-        double2 A = make_double2(0.0, 0.0), B = A;
-        if (La < nLines) A = *(const double2 *)(src + La * n + 2 * j);
-        if (La + 1 < nLines) B = *(const double2 *)(src + (La + 1) * n + 2 * j);
-        double2 *r = rows + rr * rowStride;
-        if (!INVERSE) {
-            r[padi(j)] = make_double2(A.x, B.x);               // x[2j]   -> v[j]
-            r[padi(n - 1 - j)] = make_double2(A.y, B.y);       // x[2j+1] -> v[n-1-j]
-        } else {
-            r[padi(2 * j)] = make_double2(A.x, B.x);
-            r[padi(2 * j + 1)] = make_double2(A.y, B.y);
+    // ---- load: two consecutive elements of both lines per lane; DCT_BATCH iterations' worth of
+    // 16-byte global loads are issued before the first LDS write so that their latencies overlap ----
+    for (int b0 = lane; b0 < total; b0 += 64 * DCT_BATCH) {
+        double2 A[DCT_BATCH], B[DCT_BATCH];
+#pragma unroll
+        for (int u = 0; u < DCT_BATCH; ++u) {
+            const int b = b0 + 64 * u;
+            const int rr = b >> lh, j = b & ((1 << lh) - 1);
+            const i64 La = 2 * (pair0 + rr);
+            A[u] = make_double2(0.0, 0.0);
+            B[u] = A[u];
+            if (b < total && La < nLines) A[u] = *(const double2 *)(src + La * n + 2 * j);
+            if (b < total && La + 1 < nLines) B[u] = *(const double2 *)(src + (La + 1) * n + 2 * j);
+        }
+#pragma unroll
+        for (int u = 0; u < DCT_BATCH; ++u) {
+            const int b = b0 + 64 * u;
+            if (b >= total) break;
+            const int rr = b >> lh, j = b & ((1 << lh) - 1);
+            double2 *r = rows + rr * rowStride;
+            if (!INVERSE) {
+                r[padi(j)] = make_double2(A[u].x, B[u].x);               // x[2j]   -> v[j]
+                r[padi(n - 1 - j)] = make_double2(A[u].y, B[u].y);       // x[2j+1] -> v[n-1-j]
+            } else {
+                r[padi(2 * j)] = make_double2(A[u].x, B[u].x);
+                r[padi(2 * j + 1)] = make_double2(A[u].y, B[u].y);
+            }
         }
     }
     wave_lds_sync();
@@ -333,9 +347,19 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
         const i64 L = L0 + 2 * r;
         const bool ok = L < map.nLines;
         const i64 lb = ok ? map.base(L) : 0;
-        for (int k = tid >> lp; k < n; k += DCT_THREADS >> lp) {
-            const double2 g = ok ? *(const double2 *)(src + lb + (i64)k * map.nin) : make_double2(0.0, 0.0);
-            lds[r * rowStride + padi(MODE == 1 ? k : makhoul(k, n))] = g;
+        const int kstep = DCT_THREADS >> lp;
+        for (int k0 = tid >> lp; k0 < n; k0 += kstep * DCT_BATCH) {
+            double2 gv[DCT_BATCH];
+#pragma unroll
+            for (int u = 0; u < DCT_BATCH; ++u) {
+                const int k = k0 + u * kstep;
+                gv[u] = (ok && k < n) ? *(const double2 *)(src + lb + (i64)k * map.nin) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < DCT_BATCH; ++u) {
+                const int k = k0 + u * kstep;
+                if (k < n) lds[r * rowStride + padi(MODE == 1 ? k : makhoul(k, n))] = gv[u];
+            }
         }
     } else {
         const int l = tid & (2 * npairs - 1);

@@ -56,6 +56,10 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             double b[10], v[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+            if (a.bpend) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
+            }
             build_z2(v, a.q[i], cur, nxt, c.s, c.dF);
             if (MODE != 0) {
                 const EdgeQuad nxto = load_edges(g, a.q_old, yc, xc, tl + 1, c.sf);

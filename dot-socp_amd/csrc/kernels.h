@@ -61,6 +61,10 @@ struct FusedArgs {
     double *q2;             // modes 0, 1: adjoint sums, q layout
     double *sx, *sy;        // modes 0, 1: tile-boundary partial sums
     i64 TC;
+    // pending scaling of beta_in (sigma update / rescale block, solver_socp_inPALM.m:176,313), applied on
+    // load exactly like k_scale would have: b = b * bmul / bdiv
+    int bpend;
+    double bmul, bdiv;
 };
 int fused_geometry(const Grid &g, FusedGeom &fg);
 // mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z;

@@ -216,6 +216,10 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
             double b[10], v[10], zo[10], p[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+            if (a.bpend) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
+            }
             build_z2(v, q0, cur, nxt, c.s, c.dF);
             build_z2(zo, a.q_old[i], curo, nxto, c.s, c.dF);
 #pragma unroll

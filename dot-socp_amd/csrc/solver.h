@@ -81,6 +81,13 @@ struct Solver {
     bool z_valid = true;     // s.z holds the z of the last completed iteration
     bool z_prev_ok = false;  // s.beta2 / s.q_old still hold (beta^k, q^k): z can be regenerated (MODE_Z)
     int ensure_z();
+    // fused path: a scaling of beta that the next pass over beta applies on load (saves a 20 Nz pass)
+    bool bpend = false;
+    double bmul = 1.0, bdiv = 1.0;
+    bool zp_pend = false;            // the op that was pending on the kept beta^k (beta2) when it was read
+    double zp_mul = 1.0, zp_div = 1.0;
+    int flush_beta();
+    void set_pending(FusedArgs &a) const { a.bpend = bpend ? 1 : 0; a.bmul = bmul; a.bdiv = bdiv; }
     struct Pending { hipEvent_t a, b; int phase; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;

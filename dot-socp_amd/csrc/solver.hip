@@ -393,7 +393,10 @@ int Solver::download(int field, double *host) {
     DS_ARG(field_len(field) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
     DS_HIP(hipSetDevice(device));
-    if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) DS_CHECK(ensure_z());
+    if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) {
+        DS_CHECK(ensure_z());
+        DS_CHECK(flush_beta());
+    }
     DS_CHECK(copy_field(*this, field, host, false));
     // after finish(): var.alpha = sigma * alpha, var.beta = sigma * beta  (solver_socp_inPALM.m:335-336)
     if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) {
@@ -467,12 +470,26 @@ void Solver::update_coef() {
     lc.dinv2 = 1.0 / lc.c2;
 }
 
+int Solver::flush_beta() {
+    if (!bpend) return 0;
+    for (auto &s : slabs) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul, bdiv, stream));
+    bpend = false;
+    return 0;
+}
+
 int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
+    if (fused && begun) {
+        // beta: applied by the next pass that reads it (one op can be pending at a time)
+        DS_CHECK(flush_beta());
+        bpend = true;
+        bmul = a_mul;
+        bdiv = a_div;
+    }
     for (auto &s : slabs) {
         const Grid &g = s.g;
         if (with_c) DS_CHECK(launch_scale(s.c, g.Nphi, a_mul, a_div, stream));
         DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, stream));
-        DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, stream));
+        if (!(fused && begun)) DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, stream));
         if (q_div != 1.0) {
             DS_CHECK(launch_scale(s.q, g.NqAlloc, 1.0, q_div, stream));
             DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, stream));
@@ -592,6 +609,7 @@ int Solver::phase_z() {
         a.sx = s.sx;
         a.sy = s.sy;
         a.beta_in = s.beta;
+        set_pending(a);
         if (deferred) {
             // beta^k = beta^{k-1} + tau (z^k - BF q^k - d) folded into this iteration's projection
             a.q_old = s.q_old;
@@ -603,6 +621,7 @@ int Solver::phase_z() {
         }
     }
     prof_end(ph);
+    if (deferred) bpend = false;      // mode B rewrote beta with the scaling applied
     if (multi()) {
         // adjoint sums of every slab's last cell for the first edge layer of its right neighbour
         prof_begin(PH_COMM);
@@ -655,9 +674,11 @@ int Solver::materialise() {
         a.beta_in = s.beta;
         a.beta_out = s.beta;
         a.z_out = s.z;
+        set_pending(a);
         DS_CHECK(launch_cone_fused(2, s.g, lc, s.fg, a, stream));
     }
     prof_end(PH_MATERIALISE);
+    bpend = false;
     deferred = false;
     z_valid = true;
     return 0;
@@ -678,6 +699,9 @@ int Solver::ensure_z() {
         a.q = s.q;
         a.beta_in = s.beta2;      // beta^k, kept by the KKT pass
         a.z_out = s.z;
+        a.bpend = zp_pend ? 1 : 0;
+        a.bmul = zp_mul;
+        a.bdiv = zp_div;
         DS_CHECK(launch_cone_fused(3, s.g, lc, s.fg, a, stream));
     }
     prof_end(PH_MATERIALISE);
@@ -705,14 +729,19 @@ int Solver::kkt_sums(double *S) {
             a.q = s.q;
             a.beta_in = s.beta;
             a.beta_out = s.beta2;
+            set_pending(a);
             DS_CHECK(launch_kkt_cells_update(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, stream));
             std::swap(s.beta, s.beta2);
         }
+        // the kept beta^k (now in beta2) is still unscaled in memory: remember its pending op for MODE_Z
+        zp_pend = bpend; zp_mul = bmul; zp_div = bdiv;
+        bpend = false;
         deferred = false;
         z_valid = false;
         z_prev_ok = true;
     } else {
         DS_CHECK(ensure_z());
+        DS_CHECK(flush_beta());
         rest |= 2;
     }
     if (multi()) {
@@ -929,6 +958,7 @@ int Solver::finish(dotsocp_result *res) {
     if (!begun) { set_error("finish() before begin()"); return DOTSOCP_ESTATE; }
     DS_HIP(hipSetDevice(device));
     DS_CHECK(ensure_z());
+    DS_CHECK(flush_beta());
     DS_HIP(hipStreamSynchronize(stream));
     DS_CHECK(prof_flush());
     finished = true;
