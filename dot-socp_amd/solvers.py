@@ -157,7 +157,7 @@ def solver_wsocp_inPALM(var, opts, model, device=0, nslabs=1):
 
 
 # --------------------------------------------------------------------------------------
-# drivers (levelN = 1; the multilevel transfer of jump_nextLevel.m is a "next" row)
+# drivers
 # --------------------------------------------------------------------------------------
 def _driver_opts(opts, method, weighted):
     """solver_dotsocp2d.m:76-151 / solver_dotsocp1d.m / solver_wdotsocp2d.m:85-162."""
@@ -173,25 +173,68 @@ def _driver_opts(opts, method, weighted):
     return o
 
 
-def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device):
+def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, barrier=None):
+    """The level loop of solver_dotsocp2d.m:154-250 (dot1d / wdot2d twins): restrict the data to
+    levelN grids, solve coarse to fine with warm starts; every solve runs on the device."""
+    from . import multilevel as ML
+    from .examples import ensure_barrier_validity
     if not (isinstance(levelN, (int, np.integer)) and levelN >= 1):
         raise ValueError("Invalid input at position 4 (Number of levels in multilevel strategy)")
-    if levelN != 1:
-        raise NotImplementedError("levelN > 1 (jump_nextLevel.m) is not part of this round; use levelN = 1")
     o = _driver_opts(opts, method, weighted)
-    t0 = time.perf_counter()
-    var, model = initialize(rho0, rho1, nt)
+    t_all = time.perf_counter()
+    tolFactor = -1.0 if o["tol"] > 0.99e-3 else -0.5                     # :124-128
+    tolLB = 1e-4 if dim == 2 else 1e-5                                   # :130, solver_dotsocp1d.m:121
+    L = int(levelN)
+    rho0s, rho1s, nts, tols, ws = [None] * L, [None] * L, [None] * L, [None] * L, [None] * L
+    rho0s[-1], rho1s[-1] = np.asarray(rho0, dtype=np.float64), np.asarray(rho1, dtype=np.float64)
+    nts[-1], tols[-1] = int(nt), o["tol"]
     if weighted:
-        model.weight = np.asarray(_get(opts, "weight"), dtype=np.float64)
-    InitialScaling(var, model, o["scaling"], None, dim=dim, weighted=weighted)
+        ws[-1] = np.asarray(_get(opts, "weight"), dtype=np.float64)
+    for lv in range(L - 2, -1, -1):                                      # :166-178
+        if (nts[lv + 1] - 1) % 2 or any((n - 1) % 2 for n in rho0s[lv + 1].shape):
+            raise ValueError("multilevel needs 2^k*m+1 grid sizes on every level (solver_dotsocp2d.m:167)")
+        nts[lv] = (nts[lv + 1] - 1) // 2 + 1
+        tols[lv] = max(tols[lv + 1] * 2 ** tolFactor, tolLB)
+        rho0s[lv], rho1s[lv] = ML.downSample_phi(rho0s[lv + 1]), ML.downSample_phi(rho1s[lv + 1])
+        if weighted:
+            nyf, nxf = rho0s[lv + 1].shape
+            if barrier is not None:                                      # solver_wdotsocp2d.m:186-189
+                rho0s[lv], rho1s[lv], _ = ensure_barrier_validity(rho0s[lv], rho1s[lv], barrier)
+                ws[lv] = ML.downSample_barrier(nts[lv + 1], nxf, nyf, ws[lv + 1])
+                continue
+            ws[lv] = ML.downSample_q(nts[lv + 1], nxf, nyf, ws[lv + 1])
+        N = rho0s[lv].size
+        rho0s[lv] = rho0s[lv] / (rho0s[lv].sum() / N)
+        rho1s[lv] = rho1s[lv] / (rho1s[lv].sum() / N)
+    var, model = initialize(rho0s[0], rho1s[0], nts[0])
+    if weighted:
+        model.weight = ws[0]
     solve = solver_wsocp_inPALM if weighted else solver_socp_inPALM
-    runHist, sigma = solve(var, o, model, device=device)
-    recoverOrgVar(var)
-    ml_time = time.perf_counter() - t0
-    timeML = [var.time, {"ML_Time": ml_time}]
-    runHistML = dict(runHist)
+    timeML, runHistML, runHist, last = [], None, None, None
+    for lv in range(L):
+        InitialScaling(var, model, o["scaling"], last, dim=dim, weighted=weighted)
+        runHist, sigma = solve(var, dict(o, tol=tols[lv]), model, device=device)
+        recoverOrgVar(var)
+        timeML.append(var.time)
+        if runHistML is None:                                            # catRunHist, :389-407
+            runHistML = {k: np.array(v, copy=True) if isinstance(v, np.ndarray) else v for k, v in runHist.items()}
+        else:
+            runHist["time"] = runHistML["time"][-1] + runHist["time"]
+            runHistML["kkt"] = np.concatenate([runHistML["kkt"], runHist["kkt"]], axis=0)
+            runHistML["pdGap"] = np.concatenate([runHistML["pdGap"], runHist["pdGap"]])
+            runHistML["time"] = np.concatenate([runHistML["time"], runHist["time"]])
+            runHistML["iter"] = np.concatenate([runHistML["iter"], runHistML["iter"][-1] + runHist["iter"]])
+            runHistML["len"] = runHistML["len"] + runHist["len"]
+        if lv < L - 1:
+            o["time_limit"] = o["time_limit"] - var.time["Total_Time"]   # :244
+            o["sigma"] = 10 ** (np.log10(o["sigma"] * sigma) / 2)         # :245
+            var, model = ML.jump_nextLevel(var, model, rho0s[lv + 1], rho1s[lv + 1], nts[lv + 1],
+                                           ws[lv + 1] if weighted else None)
+            last = runHist["kkt"][-1]
+    timeML.append({"ML_Time": time.perf_counter() - t_all})
     name = ("Weighted-" if weighted else "") + "DOT-SOCP"
-    runHist["method"] = runHistML["method"] = f"{method} for {name}"
+    mname = (f"{method} for {name}") if L == 1 else (f"Multilevel-{method} for {name}")
+    runHist["method"] = runHistML["method"] = mname
     return var, model, timeML, runHistML, runHist
 
 
@@ -216,7 +259,8 @@ def solver_dotsocp1d(rho0, rho1, nt, levelN, opts, method="inPALM", device=0):
 
 
 def solver_wdotsocp2d(rho0, rho1, nt, levelN, opts, method="inPALM", barrier=None, device=0):
-    var, model, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 2, True, device)
+    var, model, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 2, True, device,
+                                                          barrier=barrier)
     rho, Ex, Ey = recover_RhoE(var, model, weighted=True)
     q0, bx, by = recover_q(var, model)
     output = dict(rho=rho, Ex=Ex, Ey=Ey, q0=q0, bx=bx, by=by)

@@ -1,0 +1,105 @@
+"""Multilevel transfer operators and drivers: host-side numpy mirrors of
+jump_nextLevel.m / interpolate.m / downSample_phi.m / downSample_barrier.m / downSample_q.m.
+CPU: properties of the operators (oracle and package copies agree); GPU: levelN = 3 solves through
+the package drivers against the oracle's multilevel restatement."""
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from dotsocp_amd import multilevel as PM
+from oracle import multilevel as OM
+from oracle.driver import recover_RhoE, recover_RhoE_1d
+from oracle.examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, get_example_1d,
+                             get_example_2d, get_weight_by_barrier)
+
+rng = np.random.default_rng(7)
+
+
+def test_downsample_phi_properties():
+    for M in (OM, PM):
+        assert np.allclose(M.downSample_phi(np.ones((9, 9))), 1.0)
+        assert np.allclose(M.downSample_phi(np.ones(17)), 1.0)
+        v = rng.standard_normal((17, 17))
+        vc = M.downSample_phi(v)
+        assert vc.shape == (9, 9)
+        # interior full weighting
+        i = j = 4
+        ref = (4 * v[i, j] + 2 * (v[i - 1, j] + v[i + 1, j] + v[i, j - 1] + v[i, j + 1])
+               + v[i - 1, j - 1] + v[i - 1, j + 1] + v[i + 1, j - 1] + v[i + 1, j + 1]) / 16
+        assert abs(vc[2, 2] - ref) < 1e-15
+        with pytest.raises(ValueError):
+            M.downSample_phi(np.ones((9, 17)))          # the reference indexes both axes with the row range
+    a = rng.standard_normal((17, 17))
+    np.testing.assert_array_equal(OM.downSample_phi(a), PM.downSample_phi(a))
+    b = rng.standard_normal(33)
+    np.testing.assert_array_equal(OM.downSample_phi(b), PM.downSample_phi(b))
+
+
+def test_interpolation_reproduces_linear_functions():
+    ny, nx, nt = 5, 4, 3
+    y, x, t = np.meshgrid(np.linspace(0, 1, ny), np.linspace(0, 1, nx), np.linspace(0, 1, nt), indexing="ij")
+    f = 2 * y - 3 * x + 0.5 * t + 1
+    for M in (OM, PM):
+        fr = M.interpolate_phi(f.ravel(order="F"), (ny, nx, nt)).reshape((9, 7, 5), order="F")
+        yr, xr, tr = np.meshgrid(np.linspace(0, 1, 9), np.linspace(0, 1, 7), np.linspace(0, 1, 5), indexing="ij")
+        np.testing.assert_allclose(fr, 2 * yr - 3 * xr + 0.5 * tr + 1, atol=1e-14)
+        z = np.asfortranarray(rng.standard_normal((ny * nx * (nt - 1), 10)))
+        zr = M.interpolate_z(z, (ny, nx, nt))
+        assert zr.shape == (9 * 7 * 4, 10)
+        c = zr[:, 3].reshape((9, 7, 4), order="F")
+        co = z[:, 3].reshape((ny, nx, nt - 1), order="F")
+        np.testing.assert_array_equal(c[::2, ::2, 0], co[:, :, 0])       # nearest in t
+        np.testing.assert_array_equal(c[::2, ::2, 1], co[:, :, 0])
+        np.testing.assert_allclose(c[1, 0, 2], 0.5 * (co[0, 0, 1] + co[1, 0, 1]))
+
+
+def test_downsample_weights():
+    nt, nx, ny = 9, 9, 9
+    barrier = gene_barrier_of_circle_pillar()
+    w = get_weight_by_barrier(nx, ny, nt, barrier)
+    for M in (OM, PM):
+        wc = M.downSample_barrier(nt, nx, ny, w)
+        assert wc.size == 5 * 5 * 4 + 5 * 4 * 5 + 4 * 5 * 5
+        assert wc.min() >= 1 - 1e-12 and wc.max() <= 1e6 * (1 + 1e-12)
+        np.testing.assert_allclose(M.downSample_q(nt, nx, ny, np.ones_like(w)), 1.0, atol=1e-14)
+    np.testing.assert_allclose(OM.downSample_barrier(nt, nx, ny, w), PM.downSample_barrier(nt, nx, ny, w), rtol=1e-15)
+
+
+@pytest.mark.gpu
+def test_multilevel_dot2d_against_oracle():
+    rho0, rho1 = get_example_2d("example1", 33, 33)
+    ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, 17, 3, dict(tol=1e-4))
+    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 17, 3, dict(tol=1e-4), "inPALM")
+    assert len(timeML) == 4
+    assert [int(t["Iters"]) for t in timeML[:3]] == [int(h["iter"][-1]) for h in ohists]
+    assert histML["len"] == sum(h["len"] for h in ohists)
+    rho_o, _, _ = recover_RhoE(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-7)
+    assert D.check_massConservation(out["rho"], 1e-2)
+    assert hist["method"].startswith("Multilevel-inPALM")
+
+
+@pytest.mark.gpu
+def test_multilevel_dot1d_against_oracle():
+    rho0, rho1 = get_example_1d("gaussian", 129)
+    ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, 33, 3, dict(tol=1e-4))
+    out, timeML, histML, hist = D.solver_dotsocp1d(rho0, rho1, 33, 3, dict(tol=1e-4), "inPALM")
+    assert [int(t["Iters"]) for t in timeML[:3]] == [int(h["iter"][-1]) for h in ohists]
+    rho_o, _ = recover_RhoE_1d(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_multilevel_wdot2d_with_barrier_against_oracle():
+    n, nt = 33, 17
+    barrier = gene_barrier_of_circle_pillar()
+    rho0, rho1 = get_example_2d("example1", n, n)
+    weight = get_weight_by_barrier(n, n, nt, barrier)
+    rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    opts = dict(tol=1e-3, maxit=400)
+    ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, nt, 2, opts, weight=weight, barrier=barrier,
+                                                       ensure_barrier=ensure_barrier_validity)
+    out, timeML, histML, hist = D.solver_wdotsocp2d(rho0, rho1, nt, 2, dict(opts, weight=weight), "inPALM", barrier)
+    assert [int(t["Iters"]) for t in timeML[:2]] == [int(h["iter"][-1]) for h in ohists]
+    rho_o, _, _ = recover_RhoE(ovar, omodel, weighted=True)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-5)
