@@ -431,7 +431,13 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
     }
 }
 
-// Dense fallback: out_k = sum_j M[j*n + k] in_j from an LDS-staged tile of TL lines.
+// Dense fallback (any length n): out_k = sum_j M[j*n + k] in_j.  A workgroup stages TL lines in
+// LDS and produces the outputs k in [blockIdx.y * KC, +KC) of each of them.
+//   axis 0 (lines contiguous):  thread <-> k, accumulating all TL lines per load of M (M is read once
+//                               per TL lines);  KC = 256
+//   strided axes (LINE_FAST):   thread <-> (line, k) with the line index fastest so that global
+//                               accesses stay coalesced;  KC = 256 / TL
+#define DENSE_TL 8
 template <bool LINE_FAST>
 __global__ void __launch_bounds__(DCT_THREADS) k_dct_dense(const double *__restrict__ src, double *__restrict__ dst,
                                                             LineMap map, int n, int TL,
@@ -447,15 +453,32 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_dense(const double *__restr
         tile[l * n + k] = (L < map.nLines) ? src[map.addr(L, k)] : 0.0;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < total; e += DCT_THREADS) {
-        int l, k;
-        if (LINE_FAST) { l = e % TL; k = e / TL; } else { k = e % n; l = e / n; }
+    if (LINE_FAST) {
+        const int KC = DCT_THREADS / TL;
+        const int l = threadIdx.x % TL, k = blockIdx.y * KC + threadIdx.x / TL;
         const i64 L = L0 + l;
-        if (L >= map.nLines) continue;
+        if (k >= n || L >= map.nLines) return;
         const double *in = tile + l * n;
         double acc = 0.0;
+#pragma unroll 4
         for (int j = 0; j < n; ++j) acc += M[(i64)j * n + k] * in[j];
         dst[map.addr(L, k)] = acc;
+    } else {
+        const int k = blockIdx.y * DCT_THREADS + threadIdx.x;
+        if (k >= n) return;
+        double acc[DENSE_TL];
+#pragma unroll
+        for (int l = 0; l < DENSE_TL; ++l) acc[l] = 0.0;
+#pragma unroll 2
+        for (int j = 0; j < n; ++j) {
+            const double m = M[(i64)j * n + k];
+#pragma unroll
+            for (int l = 0; l < DENSE_TL; ++l)
+                if (l < TL) acc[l] += m * tile[l * n + j];
+        }
+#pragma unroll
+        for (int l = 0; l < DENSE_TL; ++l)
+            if (l < TL && L0 + l < map.nLines) dst[map.addr(L0 + l, k)] = acc[l];
     }
 }
 
@@ -578,16 +601,20 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             set_error("dense DCT path needs distinct src/dst");
             return DOTSOCP_EINVAL;
         }
-        int TL = (int)(65536 / (n * 8));
-        if (TL > 16) TL = 16;
-        if (TL < 1) TL = 1;
+        int TL = DENSE_TL;
+        while (TL > 1 && (size_t)TL * n * sizeof(double) > 65536) TL >>= 1;
+        while (TL > 1 && map.nLines < (i64)TL * 64) TL >>= 1;      // few lines: favour more workgroups
         const size_t lds = (size_t)TL * n * sizeof(double);
-        const unsigned blocks = (unsigned)((map.nLines + TL - 1) / TL);
+        const unsigned bx = (unsigned)((map.nLines + TL - 1) / TL);
         const double *M = inverse ? p->Cinv : p->Cfwd;
-        if (axis != 0)
-            hipLaunchKernelGGL((k_dct_dense<true>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, TL, M);
-        else
-            hipLaunchKernelGGL((k_dct_dense<false>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, TL, M);
+        if (axis != 0) {
+            const int KC = DCT_THREADS / TL;
+            hipLaunchKernelGGL((k_dct_dense<true>), dim3(bx, (unsigned)((n + KC - 1) / KC)), dim3(DCT_THREADS), lds, st, src,
+                               dst, map, (int)n, TL, M);
+        } else {
+            hipLaunchKernelGGL((k_dct_dense<false>), dim3(bx, (unsigned)((n + DCT_THREADS - 1) / DCT_THREADS)),
+                               dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, TL, M);
+        }
     }
     DS_HIP(hipGetLastError());
     return 0;
