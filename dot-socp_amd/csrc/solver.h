@@ -45,7 +45,10 @@ struct Solver {
     dotsocp_problem prob{};
     int device = 0;
     i64 ny = 0, nx = 0, nt = 0;     // internal dims (1-D problems: ny = nx1d, nx = 1)
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: everything but the overlapped cone pass; all communication
+    hipStream_t stream_z = nullptr;    // cone pass when it overlaps the phi step
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process
     int world = 1;                  // total number of slabs
     int rank = 0;                   // RCCL mode: this process's slab
@@ -111,7 +114,8 @@ struct Solver {
     int step(bool *brk);
     int rescale_block();
     int phase_phi();
-    int phase_z();
+    int phase_z(hipStream_t st);
+    int phase_z_tails();
     int phase_q();
     int phase_mult();
     int materialise();
@@ -120,8 +124,8 @@ struct Solver {
     int scale_state(double a_mul, double a_div, double q_div, bool with_c);
     void update_coef();
     double elapsed() const;
-    void prof_begin(int phase);
-    void prof_end(int phase);
+    void prof_begin(int phase, hipStream_t st = nullptr);
+    void prof_end(int phase, hipStream_t st = nullptr);
     int prof_flush();
     int poisson_all();
     int transpose(bool forward);

@@ -69,6 +69,9 @@ Solver::~Solver() {
     if (h_sums) (void)hipHostFree(h_sums);
     for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : event_pool) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (stream_z) (void)hipStreamDestroy(stream_z);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -122,6 +125,11 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_ARG(dev >= 0 && dev < ndev, "device ordinal out of range");
     DS_HIP(hipSetDevice(dev));
     DS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DS_HIP(hipStreamCreateWithFlags(&stream_z, hipStreamNonBlocking));
+    DS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    DS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    overlap = nslabs > 1;                         // pays when there is communication to hide
+    if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
     DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
     DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
     py = dct_plan_create(ny);
@@ -215,6 +223,7 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     nccl = comm;
     world = wd;
     rank = rk;
+    if (!getenv("DOTSOCP_OVERLAP")) overlap = wd > 1;
     DS_CHECK(alloc_slabs(rk, 1));
     DS_HIP(hipStreamSynchronize(stream));
     return 0;
@@ -409,8 +418,9 @@ int Solver::download(int field, double *host) {
 // --------------------------------------------------------------------------------------
 // profiling helpers
 // --------------------------------------------------------------------------------------
-void Solver::prof_begin(int phase) {
+void Solver::prof_begin(int phase, hipStream_t st) {
     if (!profiling) return;
+    if (!st) st = stream;
     Pending p;
     p.phase = phase;
     auto get = [&]() {
@@ -421,14 +431,15 @@ void Solver::prof_begin(int phase) {
     };
     p.a = get();
     p.b = get();
-    (void)hipEventRecord(p.a, stream);
+    (void)hipEventRecord(p.a, st);
     pending.push_back(p);
 }
 
-void Solver::prof_end(int phase) {
+void Solver::prof_end(int phase, hipStream_t st) {
     if (!profiling) return;
+    if (!st) st = stream;
     for (auto it2 = pending.rbegin(); it2 != pending.rend(); ++it2)
-        if (it2->phase == phase) { (void)hipEventRecord(it2->b, stream); break; }
+        if (it2->phase == phase) { (void)hipEventRecord(it2->b, st); break; }
 }
 
 int Solver::prof_flush() {
@@ -591,17 +602,19 @@ int Solver::phase_phi() {
     return 0;
 }
 
-int Solver::phase_z() {
+// The cone pass needs q^k and beta only -- not phi^{k+1} -- so it may run on `st` = stream_z
+// concurrently with the phi step (rhs, Poisson solve and, in time-slab mode, its transposes).
+int Solver::phase_z(hipStream_t st) {
     if (!fused) {
-        prof_begin(PH_PROJ);
-        for (auto &s : slabs) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, stream));
-        prof_end(PH_PROJ);
+        prof_begin(PH_PROJ, st);
+        for (auto &s : slabs) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, st));
+        prof_end(PH_PROJ, st);
         return 0;
     }
     const int ph = deferred ? PH_FUSED_B : PH_FUSED_A;
     z_valid = false;          // the fused pass forms z^{k+1} in registers only
     z_prev_ok = false;        // ... and (mode B) overwrites the kept beta^{k-1}
-    prof_begin(ph);
+    prof_begin(ph, st);
     for (auto &s : slabs) {
         FusedArgs a{};
         a.q = s.q;
@@ -614,15 +627,20 @@ int Solver::phase_z() {
             // beta^k = beta^{k-1} + tau (z^k - BF q^k - d) folded into this iteration's projection
             a.q_old = s.q_old;
             a.beta_out = s.beta2;
-            DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, stream));
+            DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, st));
             std::swap(s.beta, s.beta2);
         } else {
-            DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, stream));
+            DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, st));
         }
     }
-    prof_end(ph);
+    prof_end(ph, st);
     if (deferred) bpend = false;      // mode B rewrote beta with the scaling applied
-    if (multi()) {
+    return 0;
+}
+
+// time-slab mode: ship the adjoint sums of every slab's last cell to its right neighbour (main stream)
+int Solver::phase_z_tails() {
+    if (fused && multi()) {
         // adjoint sums of every slab's last cell for the first edge layer of its right neighbour
         prof_begin(PH_COMM);
         for (auto &s : slabs)
@@ -925,8 +943,19 @@ int Solver::step(bool *brk) {
     *brk = false;
     it += 1;
     DS_CHECK(rescale_block());
-    DS_CHECK(phase_phi());
-    DS_CHECK(phase_z());
+    if (overlap) {
+        // fork: cone pass on stream_z beside the phi step on the main stream, join before the q-step
+        DS_HIP(hipEventRecord(ev_fork, stream));
+        DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
+        DS_CHECK(phase_z(stream_z));
+        DS_HIP(hipEventRecord(ev_join, stream_z));
+        DS_CHECK(phase_phi());
+        DS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    } else {
+        DS_CHECK(phase_phi());
+        DS_CHECK(phase_z(stream));
+    }
+    DS_CHECK(phase_z_tails());
     DS_CHECK(phase_q());
     DS_CHECK(phase_mult());
     const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
