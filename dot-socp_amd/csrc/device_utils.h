@@ -92,5 +92,34 @@ struct WPlain {
     __device__ __forceinline__ double operator()(int j, i64 cell) const { return w[j * Nz + cell]; }
 };
 
+// rhs = A'(w.*q - alpha) + c at node (y, x, tl): sum over the (up to) six staggered neighbours in the
+// column order of the reference's sparse product, Neumann: missing ones dropped
+// (solver_socp_inPALM.m:194; weighted: solver_wsocp_inPALM.m:200).  Shared by k_rhs and by the
+// first DCT pass of the Poisson solve, which forms rhs on the fly.
+struct RhsArgs {
+    Grid g;
+    double at, ax, ay;
+    const double *q, *alpha, *cvec, *weight, *u0_prev;
+};
+
+template <bool WEIGHTED>
+__device__ __forceinline__ double rhs_value(const RhsArgs &a, i64 y, i64 x, i64 tl) {
+    const Grid &g = a.g;
+    auto u = [&](i64 k) { return WEIGHTED ? a.weight[k] * a.q[k] - a.alpha[k] : a.q[k] - a.alpha[k]; };
+    const i64 node = y + g.ny * (x + g.nx * tl);
+    double r = 0.0;
+    if (tl >= 1)
+        r += a.at * u(node - g.plane);
+    else if (!g.first)
+        r += a.at * a.u0_prev[y + g.ny * x];
+    if (tl < g.ncl) r += (-a.at) * u(node);
+    const i64 bxo = g.offBx + g.bxLayer * tl;
+    if (x >= 1) r += a.ax * u(bxo + y + g.ny * (x - 1));
+    if (x <= g.nx - 2) r += (-a.ax) * u(bxo + y + g.ny * x);
+    const i64 byo = g.offBy + g.byLayer * tl;
+    if (y >= 1) r += a.ay * u(byo + (y - 1) + (g.ny - 1) * x);
+    if (y <= g.ny - 2) r += (-a.ay) * u(byo + y + (g.ny - 1) * x);
+    return r + a.cvec[node];
+}
 
 }  // namespace dotsocp

@@ -17,45 +17,22 @@ static inline dim3 tile_grid(const Grid &g, i64 layers) {
 // (solver_socp_inPALM.m:194; weighted: solver_wsocp_inPALM.m:200)
 // ---------------------------------------------------------------------------------------
 template <bool WEIGHTED>
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs(Grid g, LoopCoef c, const double *__restrict__ q,
-                                                         const double *__restrict__ alpha,
-                                                         const double *__restrict__ cvec,
-                                                         const double *__restrict__ weight,
-                                                         const double *__restrict__ u0_prev,
-                                                         double *__restrict__ rhs) {
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs(RhsArgs a, double *__restrict__ rhs) {
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
-    if (y >= g.ny || x >= g.nx) return;
-    auto u = [&](i64 k) { return WEIGHTED ? weight[k] * q[k] - alpha[k] : q[k] - alpha[k]; };
-    const i64 node = y + g.ny * (x + g.nx * tl);
-    double r = 0.0;
-    // Dt' : cell t-1/2 enters with +D/ht, cell t+1/2 with -D/ht
-    if (tl >= 1)
-        r += c.at * u(node - g.plane);
-    else if (!g.first)
-        r += c.at * u0_prev[y + g.ny * x];
-    if (tl < g.ncl) r += (-c.at) * u(node);
-    // Dx'
-    const i64 bxo = g.offBx + g.bxLayer * tl;
-    if (x >= 1) r += c.ax * u(bxo + y + g.ny * (x - 1));
-    if (x <= g.nx - 2) r += (-c.ax) * u(bxo + y + g.ny * x);
-    // Dy'
-    const i64 byo = g.offBy + g.byLayer * tl;
-    if (y >= 1) r += c.ay * u(byo + (y - 1) + (g.ny - 1) * x);
-    if (y <= g.ny - 2) r += (-c.ay) * u(byo + y + (g.ny - 1) * x);
-    rhs[node] = r + cvec[node];
+    if (y >= a.g.ny || x >= a.g.nx) return;
+    rhs[y + a.g.ny * (x + a.g.nx * tl)] = rhs_value<WEIGHTED>(a, y, x, tl);
 }
 
 int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *alpha, const double *cvec,
                const double *weight, const double *u0_prev, double *rhs, hipStream_t st) {
     if (g.Nphi <= 0) return 0;
+    RhsArgs a{g, c.at, c.ax, c.ay, q, alpha, cvec, weight, u0_prev};
     if (weight)
-        hipLaunchKernelGGL(k_rhs<true>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, q, alpha, cvec, weight,
-                           u0_prev, rhs);
+        hipLaunchKernelGGL(k_rhs<true>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, a, rhs);
     else
-        hipLaunchKernelGGL(k_rhs<false>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, q, alpha, cvec,
-                           weight, u0_prev, rhs);
+        hipLaunchKernelGGL(k_rhs<false>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, a, rhs);
     DS_HIP(hipGetLastError());
     return 0;
 }
