@@ -108,6 +108,7 @@ struct Solver {
 
     // internals
     int alloc_slabs(int first, int count);
+    int ensure_alloc();
     void free_slabs();
     bool multi() const { return world > 1; }
     bool remote() const { return nccl != nullptr; }

@@ -144,7 +144,15 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_CHECK(make_eig_table(&ct, nt));
     world = nslabs;
     rank = 0;
-    DS_CHECK(alloc_slabs(0, nslabs));
+    // device arrays are allocated on first use (upload / begin) or by attach_rccl(), so that a process
+    // that is about to become one rank of many never allocates the whole grid
+    return 0;
+}
+
+int Solver::ensure_alloc() {
+    if (!slabs.empty()) return 0;
+    DS_HIP(hipSetDevice(device));
+    DS_CHECK(alloc_slabs(remote() ? rank : 0, remote() ? 1 : world));
     DS_HIP(hipStreamSynchronize(stream));
     return 0;
 }
@@ -210,7 +218,10 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     DS_ARG(id != nullptr, "unique id is NULL");
     DS_ARG(wd >= 1 && rk >= 0 && rk < wd, "bad rank / world");
     DS_ARG(wd <= nt / 2, "world must not exceed nt/2 time slabs");
-    if (begun || world != 1) { set_error("attach_rccl() must directly follow create(..., nslabs = 1)"); return DOTSOCP_ESTATE; }
+    if (begun || world != 1 || !slabs.empty()) {
+        set_error("attach_rccl() must directly follow create(..., nslabs = 1)");
+        return DOTSOCP_ESTATE;
+    }
     if (!fused) { set_error("time slabs need the fused dataflow (unset DOTSOCP_FUSED=0)"); return DOTSOCP_EINVAL; }
     DS_HIP(hipSetDevice(device));
     Rccl &api = rccl_api();
@@ -224,7 +235,7 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     world = wd;
     rank = rk;
     if (!getenv("DOTSOCP_OVERLAP")) overlap = wd > 1;
-    DS_CHECK(alloc_slabs(rk, 1));
+    DS_CHECK(ensure_alloc());
     DS_HIP(hipStreamSynchronize(stream));
     return 0;
 }
@@ -394,6 +405,7 @@ int Solver::upload(int field, const double *host) {
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "weight uploaded to an unweighted problem");
     if (begun) { set_error("upload() after begin()"); return DOTSOCP_ESTATE; }
     DS_HIP(hipSetDevice(device));
+    DS_CHECK(ensure_alloc());
     return copy_field(*this, field, const_cast<double *>(host), true);
 }
 
@@ -402,6 +414,7 @@ int Solver::download(int field, double *host) {
     DS_ARG(field_len(field) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
     DS_HIP(hipSetDevice(device));
+    DS_CHECK(ensure_alloc());
     if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) {
         DS_CHECK(ensure_z());
         DS_CHECK(flush_beta());
@@ -515,6 +528,7 @@ int Solver::begin(const dotsocp_opts *o) {
     DS_ARG(o->sigma > 0, "opts.sigma must be positive");
     if (begun) { set_error("begin() called twice"); return DOTSOCP_ESTATE; }
     DS_HIP(hipSetDevice(device));
+    DS_CHECK(ensure_alloc());
     opts = *o;
     checkPrimDualFeas = (o->checkPrimDualFeas < 0) ? !prob.weighted : (o->checkPrimDualFeas != 0);   // :20-24 / wsocp :25-29
     time_limit = (o->time_limit > 0) ? o->time_limit : 3600.0;                                        // :26-30

@@ -172,7 +172,38 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
     const i64 node = y + g.ny * (x + g.nx * tl);
-    if (SEG == 0) {
+    if (SEG == 3) {
+        // one launch for all three kinds of entries: the thread of node (y, x, tl) owns the q0 entry of
+        // the cell that starts there and the bx / by edges that leave it; phi(node) is loaded once
+        if (y >= g.ny || x >= g.nx) return;
+        const double p0 = phi[node];
+        if (tl < g.ncl) {
+            double tmp = (-c.at) * p0;
+            tmp += c.at * phi[node + g.plane];
+            q_update<WEIGHTED>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha);
+        }
+        const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
+        const double dc = tbnd ? c.c2 : c.c1;
+        const double di = tbnd ? c.dinv2 : c.dinv1;
+        if (x < g.nx - 1) {
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            double tmp = (-c.ax) * p0;
+            tmp += c.ax * phi[node + g.ny];
+            double q2 = q2v[e];
+            if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
+            if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+        }
+        if (y < g.ny - 1) {
+            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            double tmp = (-c.ay) * p0;
+            tmp += c.ay * phi[node + 1];
+            double q2 = q2v[e];
+            if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
+            if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+        }
+    } else if (SEG == 0) {
         if (y >= g.ny || x >= g.nx) return;
         double tmp = (-c.at) * phi[node];
         tmp += c.at * phi[node + g.plane];
@@ -209,15 +240,8 @@ static int launch_qstep_fused_t(const Grid &g, const LoopCoef &c, const FusedGeo
                                 const double *tail_bx, const double *tail_by, double *q, double *alpha,
                                 hipStream_t st) {
     dim3 blk(TILE_Y, TILE_X);
-    if (g.Nz > 0)
-        hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 0>), tile_grid(g, g.ncl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
-                           tail_bx, tail_by, q, alpha);
-    if (g.bxLayer > 0)
-        hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
-                           tail_bx, tail_by, q, alpha);
-    if (g.byLayer > 0)
-        hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 2>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
-                           tail_bx, tail_by, q, alpha);
+    hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 3>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
+                       tail_bx, tail_by, q, alpha);
     DS_HIP(hipGetLastError());
     return 0;
 }
