@@ -38,6 +38,8 @@ def parse_args():
                     help="override the grid (default 1024 1024 128)")
     ap.add_argument("--workload", choices=["dot2d", "wdot2d", "dot1d"], default="dot2d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nslabs", type=int, default=1,
+                    help="diagnostics: run the time-slab algorithm with this many slabs inside ONE process / GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -159,7 +161,8 @@ def main():
         t0s, t1s = D.capi.slab_range(nt, world, rank)
         var, model = D.initialize_slab(rho0, rho1, nt, t0s, t1s)
         D.InitialScaling(var, model, True, None, dim=2)
-    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False, rccl=rccl)
+    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False, rccl=rccl,
+                          nslabs=args.nslabs)
 
     def fence():
         ctx.synchronize()

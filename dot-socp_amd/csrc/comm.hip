@@ -11,8 +11,11 @@ Rccl &rccl_api() {
 
 int Rccl::load() {
     if (handle) return 0;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // DOTSOCP_RCCL_LIB: explicit library path (the test suite points it at tests/fake_rccl to run several
+    // ranks on one GPU); otherwise the system / already-loaded RCCL
+    const char *names[] = {getenv("DOTSOCP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
+        if (!nm || !*nm) continue;
         handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (handle) break;
     }

@@ -1,0 +1,103 @@
+"""One process per slab -- the production multi-GPU structure -- on the single GPU of the test box.
+RCCL refuses several ranks on one device, so the ranks talk through tests/fake_rccl (a shared-memory
+stand-in loaded via DOTSOCP_RCCL_LIB, test infrastructure only).  What this exercises is libdotsocp's
+own rank logic: dotsocp_attach_rccl, local uploads / downloads, shift() (who sends which layer to
+whom), the slab<->pencil transposes with one send/recv per peer, and the all-reduced KKT sums."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE_DIR = os.path.join(ROOT, "tests", "fake_rccl")
+FAKE_SO = os.path.join(FAKE_DIR, "libfake_rccl.so")
+pytestmark = pytest.mark.gpu
+
+NY, NX, NT, K = 32, 24, 16, 25
+
+
+def _build_fake():
+    src = os.path.join(FAKE_DIR, "fake_rccl.cpp")
+    if not os.path.exists(FAKE_SO) or os.path.getmtime(FAKE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-Wno-unused-result", "-o", FAKE_SO, src])
+
+
+def _worker(rank, world, uid_hex, q):
+    os.environ["DOTSOCP_RCCL_LIB"] = FAKE_SO
+    sys.path.insert(0, ROOT)
+    try:
+        import dotsocp_amd as D
+        from oracle import driver as OD
+        from oracle.examples import get_example_2d
+        rho0, rho1 = get_example_2d("example1", NY, NX)
+        t0, t1 = D.capi.slab_range(NT, world, rank)
+        var, model = D.initialize_slab(rho0, rho1, NT, t0, t1)
+        o = OD.default_opts(dict(tol=0.0, maxit=K), "inPALM", False)
+        D.InitialScaling(var, model, True, None, dim=2)
+        ctx = D.InPALMContext(var, o, model, rccl=(bytes.fromhex(uid_hex), rank, world))
+        ctx.run(-1)
+        hist, sigma = ctx.finish(download=False)
+        ntl = t1 - t0
+        ncl = ntl if t1 < NT else ntl - 1
+        phi = ctx.download(D.capi.F_PHI, np.empty(NY * NX * ntl))
+        nq = NY * NX * ncl + (NY * (NX - 1) + (NY - 1) * NX) * ntl
+        qv = ctx.download(D.capi.F_Q, np.empty(nq))
+        beta = ctx.download(D.capi.F_BETA, np.empty((NY * NX * ncl, 10)))
+        ctx.close()
+        q.put((rank, "ok", t0, t1, phi, qv, beta, hist["kkt"], hist["iter"], sigma))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_process_per_slab_matches_single_process(world):
+    import multiprocessing as mp
+    _build_fake()
+    sys.path.insert(0, ROOT)
+    import dotsocp_amd as D
+    from oracle import driver as OD
+    from oracle.examples import get_example_2d
+    # single-process reference
+    rho0, rho1 = get_example_2d("example1", NY, NX)
+    var, model = D.initialize(rho0, rho1, NT)
+    o = OD.default_opts(dict(tol=0.0, maxit=K), "inPALM", False)
+    D.InitialScaling(var, model, True, None, dim=2)
+    hist1, sigma1 = D.solver_socp_inPALM(var, o, model)
+    phi1 = var.phi.reshape((NY, NX, NT), order="F")
+    beta1 = var.beta.reshape((NY, NX, NT - 1, 10), order="F")
+    qi = var.qInd
+    q0_1 = var.q[:qi.bx].reshape((NY, NX, NT - 1), order="F")
+    bx_1 = var.q[qi.bx:qi.by].reshape((NY, NX - 1, NT), order="F")
+    by_1 = var.q[qi.by:].reshape((NY - 1, NX, NT), order="F")
+
+    os.environ["DOTSOCP_RCCL_LIB"] = FAKE_SO
+    uid = D.capi.rccl_unique_id()
+    ctx = mp.get_context("spawn")
+    qu = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [qu.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for res in results:
+        assert res[1] == "ok", f"rank {res[0]}: {res[1]}"
+    tol = 1e-10
+    for rank, _, t0, t1, phi, qv, beta, kkt, iters, sigma in results:
+        ntl = t1 - t0
+        ncl = ntl if t1 < NT else ntl - 1
+        np.testing.assert_array_equal(iters, hist1["iter"])
+        np.testing.assert_allclose(kkt, hist1["kkt"], rtol=1e-7, atol=1e-10)
+        assert abs(sigma - sigma1) <= 1e-12 * sigma1
+        assert np.max(np.abs(phi.reshape((NY, NX, ntl), order="F") - phi1[:, :, t0:t1])) <= tol * np.abs(phi1).max()
+        n0 = NY * NX * ncl
+        nb = NY * (NX - 1) * ntl
+        assert np.max(np.abs(qv[:n0].reshape((NY, NX, ncl), order="F") - q0_1[:, :, t0:t0 + ncl])) <= tol * np.abs(q0_1).max()
+        assert np.max(np.abs(qv[n0:n0 + nb].reshape((NY, NX - 1, ntl), order="F") - bx_1[:, :, t0:t1])) <= tol * np.abs(bx_1).max()
+        assert np.max(np.abs(qv[n0 + nb:].reshape((NY - 1, NX, ntl), order="F") - by_1[:, :, t0:t1])) <= tol * np.abs(by_1).max()
+        # beta comes back multiplied by sigma (finish()), like the single-process run
+        b = beta.reshape((NY, NX, ncl, 10), order="F")
+        assert np.max(np.abs(b - beta1[:, :, t0:t0 + ncl])) <= 1e-9 * np.abs(beta1).max()
