@@ -130,7 +130,11 @@ struct Solver {
     int prof_flush();
     int poisson_all();
     int transpose(bool forward);
-    int exchange_q_halo();
+    int exchange_q_halo(bool with_u0);
+    int exchange_u0_tail();
+    int group_begin();
+    int group_end();
+    bool u0_fresh = false;   // u0_prev holds w.*q0 - alpha0 of the CURRENT iterate of the left neighbour
     // every slab with a neighbour in direction `dir` (+1 right, -1 left) sends `count` doubles
     // from src(slab) to dst(neighbour)
     typedef std::function<double *(Slab &)> Sel;

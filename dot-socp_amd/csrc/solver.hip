@@ -263,15 +263,41 @@ int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
     return 0;
 }
 
-// first owned bx / by layers of every slab -> halo layer of its left neighbour
-int Solver::exchange_q_halo() {
+// Several shift() calls issued as ONE RCCL group (nested groups are legal): traffic to the left and
+// to the right neighbour then shares the bidirectional links instead of queueing behind each other.
+int Solver::group_begin() {
+    if (remote()) DS_NCCL(rccl_api().GroupStart());
+    return 0;
+}
+
+int Solver::group_end() {
+    if (remote()) DS_NCCL(rccl_api().GroupEnd());
+    return 0;
+}
+
+// u0 = w.*q0 - alpha0 of every slab's last cell layer -> right neighbour (first node layer of its rhs)
+int Solver::exchange_u0_tail() {
+    if (!multi()) return 0;
+    for (auto &s : slabs)
+        if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q, s.alpha, s.weight, s.send_plane, stream));
+    DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
+    u0_fresh = true;
+    return 0;
+}
+
+// first owned bx / by layers of every slab -> halo layer of its left neighbour; with_u0: the u0 tail
+// of the new iterate travels to the right in the same group
+int Solver::exchange_q_halo(bool with_u0) {
     if (!multi()) return 0;
     prof_begin(PH_COMM);
     const i64 bxL = slabs[0].g.bxLayer, byL = slabs[0].g.byLayer;
+    DS_CHECK(group_begin());
     DS_CHECK(shift(-1, [](Slab &s) { return s.q + s.g.offBx; },
                    [](Slab &s) { return s.q + s.g.offBx + s.g.bxLayer * s.g.ntl; }, bxL));
     DS_CHECK(shift(-1, [](Slab &s) { return s.q + s.g.offBy; },
                    [](Slab &s) { return s.q + s.g.offBy + s.g.byLayer * s.g.ntl; }, byL));
+    if (with_u0) DS_CHECK(exchange_u0_tail());
+    DS_CHECK(group_end());
     prof_end(PH_COMM);
     return 0;
 }
@@ -502,6 +528,7 @@ int Solver::flush_beta() {
 }
 
 int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
+    u0_fresh = false;      // q0 / alpha0 change: the u0 tail held by the right neighbour is stale
     if (fused && begun) {
         // beta: applied by the next pass that reads it (one op can be pending at a time)
         DS_CHECK(flush_beta());
@@ -544,7 +571,7 @@ int Solver::begin(const dotsocp_opts *o) {
     update_coef();
     // alpha /= sigma, beta /= sigma, c /= sigma                                                       // :102-104
     DS_CHECK(scale_state(1.0, sigma, 1.0, true));
-    DS_CHECK(exchange_q_halo());
+    DS_CHECK(exchange_q_halo(false));
     sigmaScale = 1.0;
     it = 0;
     stopped = false;
@@ -595,11 +622,10 @@ int Solver::poisson_all() {
 
 int Solver::phase_phi() {
     const i64 plane = ny * nx;
-    if (multi()) {
+    (void)plane;
+    if (multi() && !u0_fresh) {      // normally shipped with the q halo at the end of the previous iteration
         prof_begin(PH_COMM);
-        for (auto &s : slabs)
-            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q, s.alpha, s.weight, s.send_plane, stream));
-        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, plane));
+        DS_CHECK(exchange_u0_tail());
         prof_end(PH_COMM);
     }
     prof_begin(PH_RHS);
@@ -608,12 +634,7 @@ int Solver::phase_phi() {
     prof_begin(PH_POISSON);
     DS_CHECK(poisson_all());
     prof_end(PH_POISSON);
-    if (multi()) {
-        prof_begin(PH_COMM);
-        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, plane));
-        prof_end(PH_COMM);
-    }
-    return 0;
+    return 0;                        // the phi head travels with the adjoint tails (phase_z_tails)
 }
 
 // The cone pass needs q^k and beta only -- not phi^{k+1} -- so it may run on `st` = stream_z
@@ -659,8 +680,12 @@ int Solver::phase_z_tails() {
         prof_begin(PH_COMM);
         for (auto &s : slabs)
             if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.q2, s.sx, s.sy, s.send_bx, s.send_by, stream));
+        DS_CHECK(group_begin());
+        // first phi layer of every slab -> halo layer of its left neighbour (forward time difference of the q-step)
+        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_bx; }, [](Slab &s) { return s.tail_bx; }, slabs[0].g.bxLayer));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.tail_by; }, slabs[0].g.byLayer));
+        DS_CHECK(group_end());
         prof_end(PH_COMM);
     }
     return 0;
@@ -679,7 +704,7 @@ int Solver::phase_q() {
         }
     }
     prof_end(PH_QSTEP);
-    DS_CHECK(exchange_q_halo());
+    DS_CHECK(exchange_q_halo(true));
     return 0;
 }
 
