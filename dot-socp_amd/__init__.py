@@ -12,5 +12,5 @@ from .mexops import (mexBFd, mexBFd1d, mexBFdConj, mexBFdConj1d, mexProjSoc, mir
                      oper_poisson, oper_poisson3dim)
 from .model import (InitialScaling, ModelHandle, VarHandle, check_massConservation, initialize,  # noqa: F401
                     initialize_slab, recover_q, recover_RhoE, recoverOrgVar)
-from .solvers import (InPALMContext, solver_dotsocp1d, solver_dotsocp2d, solver_socp_inPALM,  # noqa: F401
-                      solver_wdotsocp2d, solver_wsocp_inPALM)
+from .solvers import (InPALMContext, solver_dotsocp1d, solver_dotsocp2d, solver_socp_accADMM,  # noqa: F401
+                      solver_socp_inPALM, solver_wdotsocp2d, solver_wsocp_accADMM, solver_wsocp_inPALM)

@@ -37,7 +37,15 @@ class Opts(ctypes.Structure):
 
 class Result(ctypes.Structure):
     _fields_ = [("sigma", dbl), ("sigma_internal", dbl), ("cScale", dbl), ("dScale", dbl),
-                ("times", dbl * 7), ("iters", i64), ("hist_len", i64), ("stopped", ctypes.c_int)]
+                ("times", dbl * 7), ("iters", i64), ("hist_len", i64), ("stopped", ctypes.c_int),
+                ("time_extra", dbl)]
+
+
+class AccOpts(ctypes.Structure):
+    _fields_ = [("restart", i64), ("rho", dbl), ("theta", dbl)]
+
+
+METHOD_INPALM, METHOD_PALM, METHOD_ACCADMM = 0, 1, 2
 
 
 F_PHI, F_Q, F_ALPHA, F_Z, F_BETA, F_C, F_WEIGHT = range(7)
@@ -65,6 +73,7 @@ SYMBOLS = {
     "dotsocp_upload": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "dotsocp_download": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "dotsocp_begin": (ctypes.c_int, [vp, ctypes.POINTER(Opts)]),
+    "dotsocp_begin_method": (ctypes.c_int, [vp, ctypes.POINTER(Opts), ctypes.c_int, ctypes.POINTER(AccOpts)]),
     "dotsocp_run": (ctypes.c_int, [vp, i64, ctypes.POINTER(i64)]),
     "dotsocp_finish": (ctypes.c_int, [vp, ctypes.POINTER(Result)]),
     "dotsocp_get_history": (ctypes.c_int, [vp, vp, vp, vp, vp]),

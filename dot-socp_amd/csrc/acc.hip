@@ -1,0 +1,172 @@
+// Kernels of the accelerated ADMM loop (socp/dot2d/algorithms/solver_socp_accADMM.m, weighted:
+// socp/wdot2d/algorithms/solver_wsocp_accADMM.m).  Unlike inPALM, z is a state variable here (it is
+// extrapolated, so it is no longer a projection of something that can be regenerated), and every
+// variable has an anchor (Halpern) or a previous extrapolation point (theta != 2).
+//
+// k_acc_cone, per cell, with q = q^+ (the q-step result of this iteration), (z, beta) = current state:
+//   beta^+ = beta + z - (BF q^+ + d)                              multiplier step   (:236-238)
+//   z^+    = Pi_Q(BF q^+ + d - beta^+)                            z-step            (:248)
+//   MODE_RAW   : store z^+, beta^+                    (iterations with a KKT check / theta != 2)
+//   MODE_FUSED : Halpern step folded in               (:373-379)
+//                  x_new = c1 x0 + c2 ((1-rho) x + rho x^+)   for x = z, beta (x0 = anchor),
+//                store z_new, beta_new (other buffers: chunks re-read the cell in front of them) and
+//                emit q2 = F* B* (z_new + beta_new), the adjoint sums of the NEXT iteration's q-step (:229)
+//   MODE_GATHER: q2 = F* B* (z + beta) only.
+// traffic, MODE_FUSED: z, beta, z0, beta0 in + z, beta out + q + q2 = 8 (60 Nz + 2 Nq) bytes.
+// Mapping and gather: identical to the fused inPALM kernel (fused.hip / gather_tile.h).
+#include "device_utils.h"
+#include "gather_tile.h"
+#include "kernels.h"
+
+namespace dotsocp {
+
+enum { ACC_RAW = 0, ACC_FUSED = 1, ACC_GATHER = 2 };
+
+template <int MODE, int XB>
+__global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArgs a) {
+    __shared__ double2 xch[2][XB][64];
+    const int lane = threadIdx.x, xl = threadIdx.y;
+    const i64 y = (i64)blockIdx.x * 64 + lane;
+    const i64 x = (i64)blockIdx.y * XB + xl;
+    const bool inb = (y < g.ny) && (x < g.nx);
+    const i64 yc = inb ? y : 0, xc = inb ? x : 0;
+    const i64 t0 = (i64)blockIdx.z * a.TC;
+    const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
+    const bool lastChunk = (t1 == g.ncl);
+    const bool gathers = (MODE != ACC_RAW);
+    const i64 tstart = (gathers && t0 > 0) ? t0 - 1 : t0;
+    const i64 tstop = (gathers && lastChunk) ? t1 + 1 : t1;
+    const i64 nxblk = gridDim.y, nyblk = gridDim.x;
+
+    EdgeQuad cur{};
+    if (MODE != ACC_GATHER) cur = load_edges(g, a.q, yc, xc, tstart, c.sf);
+    GatherCarry gc;
+    for (i64 tl = tstart; tl < tstop; ++tl) {
+        const bool hasCell = tl < g.ncl;
+        const bool own = tl >= t0;
+        double w[10];
+        if (hasCell) {
+            const i64 i = yc + g.ny * (xc + g.nx * tl);
+            double b[10], zz[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) zz[j] = a.z_in[j * g.Nz + i];
+            if (MODE == ACC_GATHER) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) w[j] = zz[j] + b[j];
+            } else {
+                const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
+                double v[10], bp[10];
+                build_z2(v, a.q[i], cur, nxt, c.s, c.dF);
+                cur = nxt;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    double t = b[j] + zz[j];          // beta + z - z2, left to right (:238)
+                    bp[j] = t - v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = v[j] - bp[j];
+                proj_row<10>(v);                      // v = z^+
+                if (MODE == ACC_RAW) {
+                    if (own && inb) {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = bp[j];
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = v[j];
+                    }
+                } else {
+                    double zn[10], bn[10];
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        const double z0 = a.z0[j * g.Nz + i];
+                        double t = a.om_rho * zz[j];
+                        t = t + a.rho * v[j];
+                        zn[j] = a.c1 * z0 + a.c2 * t;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        const double b0 = a.beta0[j * g.Nz + i];
+                        double t = a.om_rho * b[j];
+                        t = t + a.rho * bp[j];
+                        bn[j] = a.c1 * b0 + a.c2 * t;
+                    }
+                    if (own && inb) {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zn[j];
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = bn[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) w[j] = zn[j] + bn[j];
+                }
+            }
+            if (gathers && own && inb) a.q2[i] = c.s * (w[9] - w[0]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[j] = 0.0;
+        }
+        if (gathers)
+            gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blockIdx.y, blockIdx.x,
+                            a.q2, a.sx, a.sy);
+    }
+}
+
+int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, AccArgs a, hipStream_t st) {
+    if (g.Nz <= 0) return 0;
+    a.TC = fg.TC;
+    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
+    dim3 blk(64, 4);
+    switch (mode) {
+        case ACC_RAW: hipLaunchKernelGGL((k_acc_cone<ACC_RAW, 4>), grid, blk, 0, st, g, c, a); break;
+        case ACC_FUSED: hipLaunchKernelGGL((k_acc_cone<ACC_FUSED, 4>), grid, blk, 0, st, g, c, a); break;
+        case ACC_GATHER: hipLaunchKernelGGL((k_acc_cone<ACC_GATHER, 4>), grid, blk, 0, st, g, c, a); break;
+        default: set_error("bad acc cone mode"); return DOTSOCP_EINVAL;
+    }
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Extrapolation of one state array, element-wise and in place (solver_socp_accADMM.m:369-423).
+//   x  : current state (= "Old" of the reference: the two are equal at the top of every iteration)
+//   xp : x^+ of this iteration
+//   mode 0 (Halpern, :373-379):   x = c1 aux + c2 ((1-rho) x + rho xp)            aux = anchor
+//   mode 1 (theta != 2, k == 0):  hat = (1-rho) x + rho xp ; x = (1-c1) x + c1 hat               (:390-402)
+//   mode 2 (theta != 2, k  > 0):  x = (1-c1) x + (c1+c2) hat - c2 aux             aux = hatOld  (:404-410)
+//   modes 1, 2 store hat into aux when write_aux (:420)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_acc_interp(double *__restrict__ x, const double *__restrict__ xp,
+                                                    double *__restrict__ aux, i64 n, AccCoef k, int mode,
+                                                    int write_aux) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const double xo = x[i], xn = xp[i];
+        double hat = k.om_rho * xo;
+        hat = hat + k.rho * xn;
+        double r;
+        if (mode == 0) {
+            r = k.c1 * aux[i] + k.c2 * hat;
+        } else {
+            r = k.om_c1 * xo;
+            if (mode == 1) {
+                r = r + k.c1 * hat;
+            } else {
+                r = r + k.c1c2 * hat;
+                r = r - k.c2 * aux[i];
+            }
+            if (write_aux) aux[i] = hat;
+        }
+        x[i] = r;
+    }
+}
+
+int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
+                      hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_acc_interp, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, x, xp, aux, n, k, mode,
+                       write_aux);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dotsocp

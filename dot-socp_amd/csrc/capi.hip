@@ -276,6 +276,10 @@ int dotsocp_attach_rccl(dotsocp_ctx *ctx, const unsigned char id[128], int rank,
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host) { CTX_OR_FAIL(); return ctx->s.upload(field, host); }
 int dotsocp_download(dotsocp_ctx *ctx, int field, double *host) { CTX_OR_FAIL(); return ctx->s.download(field, host); }
 int dotsocp_begin(dotsocp_ctx *ctx, const dotsocp_opts *opts) { CTX_OR_FAIL(); return ctx->s.begin(opts); }
+int dotsocp_begin_method(dotsocp_ctx *ctx, const dotsocp_opts *opts, int method, const dotsocp_acc_opts *acc) {
+    CTX_OR_FAIL();
+    return ctx->s.begin_method(opts, method, acc);
+}
 int dotsocp_run(dotsocp_ctx *ctx, dotsocp_i64 n_iters, dotsocp_i64 *done) { CTX_OR_FAIL(); return ctx->s.run(n_iters, done); }
 int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res) { CTX_OR_FAIL(); return ctx->s.finish(res); }
 
@@ -302,7 +306,8 @@ int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dots
     CTX_OR_FAIL();
     DS_ARG(name != nullptr, "name is NULL");
     static const char *names[PH_COUNT] = {"rhs", "poisson", "cone_proj", "qstep", "beta", "kkt",
-                                          "cone_fused_a", "cone_fused_b", "materialise", "comm"};
+                                          "cone_fused_a", "cone_fused_b", "materialise", "comm",
+                                          "interp", "acc_cone", "acc_gather"};
     for (int i = 0; i < PH_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) {
             const i64 n = ctx->s.phase_launches[i];

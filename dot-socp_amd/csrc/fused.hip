@@ -22,6 +22,7 @@
 // q-step adds the two.  Chunks after the first recompute the cell in front of them (reads only:
 // beta is ping-ponged, so no other workgroup's writes are observed).
 #include "device_utils.h"
+#include "gather_tile.h"
 #include "kernels.h"
 
 namespace dotsocp {
@@ -42,8 +43,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 
     EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo;
     if (MODE != 0) curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
-    double p3 = 0.0, p4 = 0.0, p7 = 0.0, p8 = 0.0;     // "t+1" cone entries of the previous cell
-    int par = 0;
+    GatherCarry gc;
     // one extra virtual step (tl == ncl, no cell) on the last chunk emits the final edge layer
     const i64 tstop = (MODE < 2 && lastChunk) ? t1 + 1 : t1;
     for (i64 tl = tstart; tl < tstop; ++tl) {
@@ -98,43 +98,9 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 #pragma unroll
             for (int j = 0; j < 10; ++j) w[j] = 0.0;
         }
-        if (MODE < 2) {
-            // ---- adjoint gather for edge layer tl: ((w1(x+1) + w2(x)) + w3'(x+1)) + w4'(x), ' = previous cell
-            xch[par][xl][lane] = make_double2(w[1], p3);
-            __syncthreads();
-            if (own && inb) {
-                if (x < g.nx - 1) {
-                    const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
-                    if (xl < XB - 1) {
-                        const double2 r = xch[par][xl + 1][lane];
-                        double acc = r.x + w[2];
-                        acc += r.y;
-                        acc += p4;
-                        a.q2[e] = c.sf * acc;
-                    } else {
-                        a.q2[e] = w[2] + p4;                        // partial; the right tile adds its part via sx
-                    }
-                }
-                if (xl == 0 && x > 0) a.sx[(tl * nxblk + blockIdx.y) * g.ny + y] = w[1] + p3;
-            }
-            const double u5 = __shfl_down(w[5], 1, 64), u7 = __shfl_down(p7, 1, 64);
-            if (own && inb) {
-                if (y < g.ny - 1) {
-                    const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
-                    if (lane < 63) {
-                        double acc = u5 + w[6];
-                        acc += u7;
-                        acc += p8;
-                        a.q2[e] = c.sf * acc;
-                    } else {
-                        a.q2[e] = w[6] + p8;                        // partial; the upper tile adds its part via sy
-                    }
-                }
-                if (lane == 0 && y > 0) a.sy[(tl * g.nx + x) * nyblk + blockIdx.x] = w[5] + p7;
-            }
-            p3 = w[3]; p4 = w[4]; p7 = w[7]; p8 = w[8];
-            par ^= 1;
-        }
+        if (MODE < 2)   // adjoint gather for edge layer tl (gather_tile.h)
+            gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blockIdx.y, blockIdx.x,
+                            a.q2, a.sx, a.sy);
     }
 }
 

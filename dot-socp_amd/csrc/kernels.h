@@ -72,6 +72,26 @@ int fused_geometry(const Grid &g, FusedGeom &fg);
 int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
                       hipStream_t st);
 
+// ---------------- acc.hip (acc-ADMM loop) ----------------
+struct AccArgs {
+    const double *q;                 // q^+ of this iteration (modes 0, 1)
+    const double *z_in, *beta_in;    // current state
+    const double *z0, *beta0;        // Halpern anchors (mode 1)
+    double *z_out, *beta_out;        // mode 0: z^+, beta^+; mode 1: new state (buffers other than the inputs)
+    double *q2, *sx, *sy;            // modes 1, 2: adjoint sums for the next q-step
+    i64 TC;
+    double c1, c2, om_rho, rho;      // Halpern weights: 1/(k+2), (k+1)/(k+2), 1 - rho, rho
+};
+struct AccCoef {
+    double c1, c2, om_rho, rho;      // as above (Halpern) or c1 = theta/(2(k+theta)), c2 = k/(k+theta)
+    double om_c1, c1c2;              // 1 - c1, c1 + c2 (theta != 2)
+};
+// mode 0: multiplier + z-step, raw outputs; 1: + Halpern step + gather; 2: gather of (z + beta) only
+int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, AccArgs a, hipStream_t st);
+// element-wise extrapolation of one state array (modes: see acc.hip)
+int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
+                      hipStream_t st);
+
 // ---------------- stencil.hip ----------------
 // q-step + alpha update reading the precomputed adjoint sums q2 (+ side buffers) of the fused kernel;
 // writes q^{k+1} into q_out (q^k stays intact for the deferred beta update).
@@ -79,6 +99,10 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *q2, const double *sx, const double *sy, const double *weight,
                        const double *tail_bx, const double *tail_by, double *q_out, double *alpha,
                        hipStream_t st);
+// acc-ADMM flavour (solver_socp_accADMM.m:229-237): same q, alpha_out = (alpha_in + A phi) - w.*q
+int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                     const double *sx, const double *sy, const double *weight, double *q_out,
+                     const double *alpha_in, double *alpha_out, hipStream_t st);
 // time-slab mode: complete the adjoint sums of the last owned cell for the right neighbour (values times sf)
 int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,
                          const double *sy, double *tail_bx, double *tail_by, hipStream_t st);

@@ -9,6 +9,24 @@
 
 namespace dotsocp {
 
+template <class T>
+inline int dmalloc(T **p, i64 n) {
+    *p = nullptr;
+    if (n <= 0) n = 1;
+    DS_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)n));
+    return 0;
+}
+
+inline int dzalloc(double **p, i64 n, hipStream_t st) {
+    DS_CHECK(dmalloc(p, n));
+    DS_HIP(hipMemsetAsync(*p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), st));
+    return 0;
+}
+
+inline void dfree(void *p) {
+    if (p) (void)hipFree(p);
+}
+
 // One time slab (common.h: Grid).  Single-GPU runs have exactly one; `nslabs` > 1 keeps several in
 // one process (the multi-GPU algorithm with device-to-device copies as "communication"); with an
 // RCCL communicator attached the process holds the single slab `rank` of `world`.
@@ -36,10 +54,16 @@ struct Slab {
     // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
     double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
     FusedGeom fg{};
+    // acc-ADMM loop (solver_acc.hip): x^+ of the iteration (q^+ lives in q_old, beta^+ in beta2) and the
+    // Halpern anchors / previous extrapolation points
+    double *phi_p = nullptr, *alpha_p = nullptr, *z_p = nullptr;
+    double *phi_a = nullptr, *q_a = nullptr, *alpha_a = nullptr, *z_a = nullptr, *beta_a = nullptr;
 };
 
+bool if_adjust_sigma(double iter, double last_iter);   // IfAdjustSigma (solver_socp_inPALM.m:361-379)
+
 enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_FUSED_A, PH_FUSED_B, PH_MATERIALISE,
-             PH_COMM, PH_COUNT };
+             PH_COMM, PH_INTERP, PH_ACC_CONE, PH_ACC_GATHER, PH_COUNT };
 
 struct Solver {
     dotsocp_problem prob{};
@@ -103,6 +127,7 @@ struct Solver {
     int upload(int field, const double *host);
     int download(int field, double *host);
     int begin(const dotsocp_opts *o);
+    int begin_method(const dotsocp_opts *o, int method, const dotsocp_acc_opts *acc);
     int run(i64 n_iters, i64 *done);
     int finish(dotsocp_result *res);
 
@@ -140,6 +165,23 @@ struct Solver {
     typedef std::function<double *(Slab &)> Sel;
     int shift(int dir, const Sel &src, const Sel &dst, i64 count);
     i64 field_len(int field) const;
+
+    // ---- loop variants (include/dotsocp.h: DOTSOCP_METHOD_*) ----
+    int method = DOTSOCP_METHOD_INPALM;
+    // acc-ADMM (solver_socp_accADMM.m:12-34,157-163)
+    i64 acc_restart = 100, acc_k = 0;
+    double acc_rho = 2.0, acc_theta = 2.0;
+    bool acc_halpern = true;
+    bool acc_gather_valid = false;     // q2 / sx / sy hold F*B*(z + beta) of the current state
+    bool acc_swapped = false;          // state and x^+ pointers are exchanged (during the KKT block / after a stop)
+    int acc_alloc();
+    int acc_begin(const dotsocp_acc_opts *acc);
+    int acc_step(bool *brk);
+    int acc_rescale_block();
+    int acc_set_anchors();
+    void acc_swap_state();
+    int acc_on_sigma_factor(double factor);
+    AccCoef acc_coef() const;
 };
 
 }  // namespace dotsocp

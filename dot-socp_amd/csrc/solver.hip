@@ -28,24 +28,6 @@ void set_error(const char *fmt, ...) {
     g_last_error = buf;
 }
 
-template <class T>
-static int dmalloc(T **p, i64 n) {
-    *p = nullptr;
-    if (n <= 0) n = 1;
-    DS_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)n));
-    return 0;
-}
-
-static int dzalloc(double **p, i64 n, hipStream_t st) {
-    DS_CHECK(dmalloc(p, n));
-    DS_HIP(hipMemsetAsync(*p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), st));
-    return 0;
-}
-
-static void dfree(void *p) {
-    if (p) (void)hipFree(p);
-}
-
 void Solver::free_slabs() {
     for (auto &s : slabs) {
         dfree(s.phi); dfree(s.q); dfree(s.alpha); dfree(s.z); dfree(s.beta); dfree(s.c); dfree(s.weight);
@@ -55,6 +37,8 @@ void Solver::free_slabs() {
         dfree(s.send_plane); dfree(s.send_plane2); dfree(s.send_bx); dfree(s.send_by);
         dfree(s.kw.partials); dfree(s.kw.sums);
         dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy);
+        dfree(s.phi_p); dfree(s.alpha_p); dfree(s.z_p);
+        dfree(s.phi_a); dfree(s.q_a); dfree(s.alpha_a); dfree(s.z_a); dfree(s.beta_a);
     }
     slabs.clear();
 }
@@ -549,6 +533,18 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
     return 0;
 }
 
+int Solver::begin_method(const dotsocp_opts *o, int m, const dotsocp_acc_opts *acc) {
+    if (begun) { set_error("begin() called twice"); return DOTSOCP_ESTATE; }
+    if (m == DOTSOCP_METHOD_INPALM) return begin(o);
+    DS_ARG(m == DOTSOCP_METHOD_ACCADMM, "unknown method");
+    DS_ARG(prob.dim == 2, "the reference has no 1-D acc-ADMM loop");
+    DS_ARG(!multi(), "acc-ADMM runs on one slab");
+    method = m;
+    int rc = begin(o);
+    if (rc != 0) { method = DOTSOCP_METHOD_INPALM; return rc; }
+    return acc_begin(acc);
+}
+
 int Solver::begin(const dotsocp_opts *o) {
     DS_ARG(o != nullptr, "opts is NULL");
     DS_ARG(o->maxit >= 0, "opts.maxit < 0");
@@ -556,6 +552,10 @@ int Solver::begin(const dotsocp_opts *o) {
     if (begun) { set_error("begin() called twice"); return DOTSOCP_ESTATE; }
     DS_HIP(hipSetDevice(device));
     DS_CHECK(ensure_alloc());
+    if (method == DOTSOCP_METHOD_ACCADMM) {
+        DS_CHECK(acc_alloc());
+        fused = false;       // z is a stored state variable of this loop: the generic helpers take their "z in memory" paths
+    }
     opts = *o;
     checkPrimDualFeas = (o->checkPrimDualFeas < 0) ? !prob.weighted : (o->checkPrimDualFeas != 0);   // :20-24 / wsocp :25-29
     time_limit = (o->time_limit > 0) ? o->time_limit : 3600.0;                                        // :26-30
@@ -878,7 +878,7 @@ int Solver::rescale_block() {
     return 0;
 }
 
-static bool if_adjust_sigma(double iter, double last_iter) {   // :361-379
+bool if_adjust_sigma(double iter, double last_iter) {   // :361-379
     const double passed = iter - last_iter;
     if (iter < 20 && passed >= 3) return true;
     if (iter < 50 && passed >= 6) return true;
@@ -969,7 +969,10 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
         else { resiPri = std::max(res[0], res[1]); resiDual = std::max(res[2], res[4]); }
         double factor;
         adjust_lagrangian_param(sigma, resiPri / resiDual, factor);
-        if (factor != 1.0) DS_CHECK(scale_state(1.0, factor, 1.0, true));
+        if (factor != 1.0) {
+            DS_CHECK(scale_state(1.0, factor, 1.0, true));
+            if (method == DOTSOCP_METHOD_ACCADMM) DS_CHECK(acc_on_sigma_factor(factor));
+        }
     }
     if (rescale > 0) {                                                      // :319-322
         maxFeas = maxRes;
@@ -980,6 +983,7 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
 
 int Solver::step(bool *brk) {
     *brk = false;
+    if (method == DOTSOCP_METHOD_ACCADMM) return acc_step(brk);
     it += 1;
     DS_CHECK(rescale_block());
     if (overlap) {
@@ -1047,6 +1051,14 @@ int Solver::finish(dotsocp_result *res) {
         res->iters = it;
         res->hist_len = (i64)hist_iter.size();
         res->stopped = stopped ? 1 : 0;
+        if (method == DOTSOCP_METHOD_ACCADMM) {
+            // Step_1_Q_Step, Step_2_Multiplier (folded into the cone pass), Step_3_1_FFT, Step_3_2_ProjSOC, KKT, Interp
+            res->times[0] = (phase_ms[PH_RHS] + phase_ms[PH_POISSON]) * 1e-3;
+            res->times[1] = phase_ms[PH_ACC_CONE] * 1e-3;
+            res->times[2] = (phase_ms[PH_QSTEP] + phase_ms[PH_ACC_GATHER]) * 1e-3;
+            res->times[3] = 0.0;
+            res->time_extra = phase_ms[PH_INTERP] * 1e-3;
+        }
     }
     return 0;
 }

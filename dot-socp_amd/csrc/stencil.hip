@@ -73,11 +73,11 @@ struct WSum {
     __device__ __forceinline__ double operator()(int j, i64 cell) const { return z[j * Nz + cell] + b[j * Nz + cell]; }
 };
 
-template <bool WEIGHTED>
+template <bool WEIGHTED, bool ACC = false>
 __device__ __forceinline__ void q_update(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
                                          const double *__restrict__ weight, double *__restrict__ q,
-                                         double *__restrict__ alpha) {
-    const double a = alpha[k];
+                                         double *alpha, const double *alpha_in = nullptr) {
+    const double a = ACC ? alpha_in[k] : alpha[k];
     double qn, r;
     if (WEIGHTED) {
         const double w = weight[k];
@@ -89,7 +89,13 @@ __device__ __forceinline__ void q_update(const LoopCoef &c, double tmp, double q
         r = tmp - qn;
     }
     q[k] = qn;
-    alpha[k] = a + c.tau * r;
+    if (ACC) {
+        // alpha + tmp_q - w.*q, left to right (solver_socp_accADMM.m:237, solver_wsocp_accADMM.m:243)
+        const double t = a + tmp;
+        alpha[k] = WEIGHTED ? t - weight[k] * qn : t - qn;
+    } else {
+        alpha[k] = a + c.tau * r;
+    }
 }
 
 template <bool WEIGHTED, int SEG>
@@ -158,7 +164,7 @@ int launch_qstep(const Grid &g, const LoopCoef &c, const double *phi, const doub
 
 // q-step on the adjoint sums produced by the fused cone kernel (fused.hip): q2 already holds
 // sf * sum for tile-interior edges and the own tile's raw partial for tile-boundary edges.
-template <bool WEIGHTED, int SEG>
+template <bool WEIGHTED, int SEG, bool ACC = false>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef c, FusedGeom fg,
                                                                  const double *__restrict__ phi,
                                                                  const double *__restrict__ q2v,
@@ -167,7 +173,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
                                                                  const double *__restrict__ weight,
                                                                  const double *__restrict__ tail_bx,
                                                                  const double *__restrict__ tail_by,
-                                                                 double *__restrict__ q, double *__restrict__ alpha) {
+                                                                 double *__restrict__ q, double *alpha,
+                                                                 const double *alpha_in) {
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
         if (tl < g.ncl) {
             double tmp = (-c.at) * p0;
             tmp += c.at * phi[node + g.plane];
-            q_update<WEIGHTED>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha);
+            q_update<WEIGHTED, ACC>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha, alpha_in);
         }
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
         const double dc = tbnd ? c.c2 : c.c1;
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
             if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];
-            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
         if (y < g.ny - 1) {
             const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
@@ -201,13 +208,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
             if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
-            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
     } else if (SEG == 0) {
         if (y >= g.ny || x >= g.nx) return;
         double tmp = (-c.at) * phi[node];
         tmp += c.at * phi[node + g.plane];
-        q_update<WEIGHTED>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha);
+        q_update<WEIGHTED, ACC>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha, alpha_in);
     } else {
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
         const double dc = tbnd ? c.c2 : c.c1;
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
             if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];      // left slab's part, already times sf
-            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         } else {
             if (y >= g.ny - 1 || x >= g.nx) return;
             const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
             if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
-            q_update<WEIGHTED>(c, tmp, q2, dc, di, e, weight, q, alpha);
+            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
     }
 }
@@ -241,7 +248,7 @@ static int launch_qstep_fused_t(const Grid &g, const LoopCoef &c, const FusedGeo
                                 hipStream_t st) {
     dim3 blk(TILE_Y, TILE_X);
     hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 3>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
-                       tail_bx, tail_by, q, alpha);
+                       tail_bx, tail_by, q, alpha, (const double *)nullptr);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -251,6 +258,21 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *tail_by, double *q_out, double *alpha, hipStream_t st) {
     return weight ? launch_qstep_fused_t<true>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st)
                   : launch_qstep_fused_t<false>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st);
+}
+
+int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                     const double *sx, const double *sy, const double *weight, double *q_out, const double *alpha_in,
+                     double *alpha_out, hipStream_t st) {
+    dim3 blk(TILE_Y, TILE_X);
+    const double *none = nullptr;
+    if (weight)
+        hipLaunchKernelGGL((k_qstep_fused<true, 3, true>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
+                           weight, none, none, q_out, alpha_out, alpha_in);
+    else
+        hipLaunchKernelGGL((k_qstep_fused<false, 3, true>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
+                           weight, none, none, q_out, alpha_out, alpha_in);
+    DS_HIP(hipGetLastError());
+    return 0;
 }
 
 // Time-slab mode: the fused cone kernel leaves, in the halo layer (index ncl) of q2 and of the side

@@ -21,6 +21,13 @@ from .model import (InitialScaling, ModelHandle, VarHandle, check_massConservati
 
 TIME_NAMES = ['Step_1_1_FFT', 'Step_1_2_ProjSOC', 'Step_2_Q_Step', 'Step_3_Multiplier', 'KKT',
               'Total_Time', 'Iters']
+# solver_socp_accADMM.m:438-439 (the weighted file lists 'Step_4_Interp' before 'KKT', :443-444)
+ACC_TIME_NAMES = ['Step_1_Q_Step', 'Step_2_Multiplier', 'Step_3_1_FFT', 'Step_3_2_ProjSOC', 'KKT', 'Interp',
+                  'Total_Time', 'Iters']
+WACC_TIME_NAMES = ['Step_1_Q_Step', 'Step_2_Multiplier', 'Step_3_1_FFT', 'Step_3_2_ProjSOC', 'Step_4_Interp', 'KKT',
+                   'Total_Time', 'Iters']
+METHODS = {"inPALM": capi.METHOD_INPALM, "ALG2": capi.METHOD_INPALM, "PALM": capi.METHOD_PALM,
+           "acc-ADMM": capi.METHOD_ACCADMM}
 
 
 def _get(opts, name, default=None):
@@ -36,10 +43,13 @@ def _has(opts, name):
 class InPALMContext:
     """Stateful handle on one device-resident loop (create -> upload -> begin -> run* -> finish)."""
 
-    def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False, rccl=None):
+    def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False, rccl=None,
+                 method="inPALM"):
         """rccl = (unique_id_bytes, rank, world): one process per GPU, this process owns time slab
-        `rank`; var / model then hold the LOCAL slab of every field (model.nt stays the global nt)."""
+        `rank`; var / model then hold the LOCAL slab of every field (model.nt stays the global nt).
+        method: which loop file of the reference runs ("inPALM"/"ALG2" by opts.tau, "acc-ADMM")."""
         L = capi.lib()
+        self.method = method
         one_d = not hasattr(model, "ny")
         p = capi.Problem()
         p.dim = 1 if one_d else 2
@@ -68,14 +78,22 @@ class InPALMContext:
                 capi.check(L.dotsocp_set_profiling(self._ctx, 1))
             o = capi.Opts()
             # required fields (solver_socp_inPALM.m:33-37)
-            o.tau, o.sigma, o.tol = float(_get(opts, "tau")), float(_get(opts, "sigma")), float(_get(opts, "tol"))
+            o.tau = float(_get(opts, "tau", 1.0) if method == "acc-ADMM" else _get(opts, "tau"))
+            o.sigma, o.tol = float(_get(opts, "sigma")), float(_get(opts, "tol"))
             o.maxit = int(_get(opts, "maxit"))
             o.ifCheckStepByStep = int(bool(_get(opts, "ifCheckStepByStep", False)))
             # optional fields (:20-30,64-68)
             o.checkPrimDualFeas = int(bool(_get(opts, "checkPrimDualFeas"))) if _has(opts, "checkPrimDualFeas") else -1
             o.scaling = int(bool(_get(opts, "scaling", False)))
             o.time_limit = float(_get(opts, "time_limit", 3600))
-            capi.check(L.dotsocp_begin(self._ctx, ctypes.byref(o)))
+            if METHODS[method] == capi.METHOD_INPALM:
+                capi.check(L.dotsocp_begin(self._ctx, ctypes.byref(o)))
+            else:
+                a = capi.AccOpts()                  # solver_socp_accADMM.m:12-28; 0 = reference default
+                a.restart = int(_get(opts, "restart", 0) or 0)
+                a.rho = float(_get(opts, "rho", 0) or 0)
+                a.theta = float(_get(opts, "theta", 0) or 0)
+                capi.check(L.dotsocp_begin_method(self._ctx, ctypes.byref(o), METHODS[method], ctypes.byref(a)))
         except Exception:
             self.close()
             raise
@@ -108,14 +126,20 @@ class InPALMContext:
         res = capi.Result()
         capi.check(L.dotsocp_finish(self._ctx, ctypes.byref(res)))
         var = self.var
-        var.name = 'Inexact Proximal ALM'
+        var.name = 'Accelerated ADMM' if self.method == "acc-ADMM" else 'Inexact Proximal ALM'
         if download:
             var.phi = self.download(capi.F_PHI, var.phi)
             var.q = self.download(capi.F_Q, var.q)
             var.z = self.download(capi.F_Z, var.z)
             var.alpha = self.download(capi.F_ALPHA, var.alpha)       # = sigma * alpha
             var.beta = self.download(capi.F_BETA, var.beta)          # = sigma * beta
-        var.time = dict(zip(TIME_NAMES, list(res.times)))
+        t = list(res.times)
+        if self.method == "acc-ADMM":
+            tm = dict(Step_1_Q_Step=t[2], Step_2_Multiplier=t[3], Step_3_1_FFT=t[0], Step_3_2_ProjSOC=t[1], KKT=t[4],
+                      Interp=res.time_extra, Step_4_Interp=res.time_extra, Total_Time=t[5], Iters=t[6])
+            var.time = {k: tm[k] for k in (WACC_TIME_NAMES if self.weighted else ACC_TIME_NAMES)}
+        else:
+            var.time = dict(zip(TIME_NAMES, t))
         var.cScale, var.dScale = res.cScale, res.dScale
         n = int(res.hist_len)
         kkt = np.empty((n, 7), order="F")
@@ -156,18 +180,40 @@ def solver_wsocp_inPALM(var, opts, model, device=0, nslabs=1):
         ctx.close()
 
 
+def solver_socp_accADMM(var, opts, model, device=0):
+    """[runHist, sigma] = solver_socp_accADMM(var, opts, model)   socp/dot2d/algorithms/solver_socp_accADMM.m:1
+    opts: sigma, maxit, tol, ifCheckStepByStep (+ restart, rho, theta, checkPrimDualFeas, time_limit, scaling)."""
+    ctx = InPALMContext(var, opts, model, weighted=False, device=device, method="acc-ADMM")
+    try:
+        ctx.run(-1)
+        return ctx.finish()
+    finally:
+        ctx.close()
+
+
+def solver_wsocp_accADMM(var, opts, model, device=0):
+    """socp/wdot2d/algorithms/solver_wsocp_accADMM.m:1"""
+    ctx = InPALMContext(var, opts, model, weighted=True, device=device, method="acc-ADMM")
+    try:
+        ctx.run(-1)
+        return ctx.finish()
+    finally:
+        ctx.close()
+
+
 # --------------------------------------------------------------------------------------
 # drivers
 # --------------------------------------------------------------------------------------
-def _driver_opts(opts, method, weighted):
+def _driver_opts(opts, method, weighted, dim=2):
     """solver_dotsocp2d.m:76-151 / solver_dotsocp1d.m / solver_wdotsocp2d.m:85-162."""
-    if method not in ("inPALM", "ALG2"):
+    if method not in ("inPALM", "ALG2") and not (method == "acc-ADMM" and dim == 2):
         raise ValueError("Invalid input at position 6 (Solving method)")
     o = dict(opts) if isinstance(opts, dict) else dict(vars(opts))
     o.setdefault("ifCheckStepByStep", False)
     o.setdefault("scaling", True)
     o.setdefault("maxit", 10000 if weighted else 3000)
-    o["tau"] = 1.9 if method == "inPALM" else 1.0
+    if method != "acc-ADMM":
+        o["tau"] = 1.9 if method == "inPALM" else 1.0
     o.setdefault("sigma", 1.0)
     o.setdefault("time_limit", 3600)
     return o
@@ -180,7 +226,7 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
     from .examples import ensure_barrier_validity
     if not (isinstance(levelN, (int, np.integer)) and levelN >= 1):
         raise ValueError("Invalid input at position 4 (Number of levels in multilevel strategy)")
-    o = _driver_opts(opts, method, weighted)
+    o = _driver_opts(opts, method, weighted, dim)
     t_all = time.perf_counter()
     tolFactor = -1.0 if o["tol"] > 0.99e-3 else -0.5                     # :124-128
     tolLB = 1e-4 if dim == 2 else 1e-5                                   # :130, solver_dotsocp1d.m:121
@@ -209,7 +255,10 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
     var, model = initialize(rho0s[0], rho1s[0], nts[0])
     if weighted:
         model.weight = ws[0]
-    solve = solver_wsocp_inPALM if weighted else solver_socp_inPALM
+    if method == "acc-ADMM":                                             # :224-225
+        solve = solver_wsocp_accADMM if weighted else solver_socp_accADMM
+    else:
+        solve = solver_wsocp_inPALM if weighted else solver_socp_inPALM
     timeML, runHistML, runHist, last = [], None, None, None
     for lv in range(L):
         InitialScaling(var, model, o["scaling"], last, dim=dim, weighted=weighted)

@@ -127,6 +127,20 @@ typedef struct {
     double time_limit;          /* seconds; <= 0 means the reference default 3600           */
 } dotsocp_opts;
 
+/* Loop variants behind the same boundary: which reference solver file the loop follows. */
+enum {
+    DOTSOCP_METHOD_INPALM = 0,  /* solver_socp_inPALM.m / solver_wsocp_inPALM.m (ALG2: tau = 1)     */
+    DOTSOCP_METHOD_PALM = 1,    /* solver_socp_PALM.m (2-D unweighted only)                          */
+    DOTSOCP_METHOD_ACCADMM = 2  /* solver_socp_accADMM.m / solver_wsocp_accADMM.m (2-D only)         */
+};
+
+/* extra options of the accelerated ADMM (solver_socp_accADMM.m:12-34); <= 0 selects the reference default */
+typedef struct {
+    dotsocp_i64 restart;        /* opts.restart, default 100                                         */
+    double rho;                 /* opts.rho, default 2                                               */
+    double theta;               /* opts.theta, default 2 (== 2: Halpern iteration)                   */
+} dotsocp_acc_opts;
+
 /* Field selectors for upload / download */
 enum {
     DOTSOCP_F_PHI = 0,   /* Nphi                                  var.phi        */
@@ -148,6 +162,7 @@ typedef struct {
     dotsocp_i64 iters;     /* iterations executed                                           */
     dotsocp_i64 hist_len;  /* runHist.len                                                   */
     int stopped;           /* 1 when the stop criterion (:287-290) fired                    */
+    double time_extra;     /* acc-ADMM: 'Interp' (solver_socp_accADMM.m:438-439); PALM: 'Step_1_Q_Step' */
 } dotsocp_result;
 
 /* `device` = HIP device ordinal.  `nslabs` >= 1 splits the time axis into that many
@@ -179,6 +194,11 @@ int dotsocp_download(dotsocp_ctx *ctx, int field, double *host);
  * to a single call.  After finish(), download PHI/Q/Z/ALPHA/BETA gives var.* of :332-336
  * (alpha and beta multiplied by sigma). */
 int dotsocp_begin(dotsocp_ctx *ctx, const dotsocp_opts *opts);
+/* Same as dotsocp_begin for another loop file of the reference: DOTSOCP_METHOD_*; `acc` may be NULL
+ * (reference defaults) and is read for DOTSOCP_METHOD_ACCADMM only.  run / finish / downloads are
+ * unchanged; result.times follows the inPALM order with the variant's extra column in time_extra.
+ * Variants other than inPALM run on one slab (no time-slab mode yet): DOTSOCP_EINVAL otherwise. */
+int dotsocp_begin_method(dotsocp_ctx *ctx, const dotsocp_opts *opts, int method, const dotsocp_acc_opts *acc);
 int dotsocp_run(dotsocp_ctx *ctx, dotsocp_i64 n_iters, dotsocp_i64 *done);
 int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res);
 

@@ -18,11 +18,11 @@ def default_opts(opts, method="inPALM", weighted=False):
     o.setdefault("ifCheckStepByStep", False)
     o.setdefault("scaling", True)
     o.setdefault("maxit", 10000 if weighted else 3000)
-    if method == "inPALM":
+    if method in ("inPALM", "PALM"):     # :133-137
         o["tau"] = 1.9
     elif method == "ALG2":
         o["tau"] = 1.0
-    else:
+    elif method != "acc-ADMM":           # acc-ADMM reads no tau (solver_socp_accADMM.m:12-60)
         raise ValueError("Invalid input at position 6 (Solving method)")
     o.setdefault("sigma", 1.0)          # `isfield(opts,"scaling")` always holds after :81-86
     o.setdefault("time_limit", 3600)
@@ -134,10 +134,21 @@ def make_level(rho0, rho1, nt, opts, method="inPALM", weight=None):
     return var, model, o
 
 
+def make_state(var, o, model, method="inPALM", weighted=False):
+    """The loop object the drivers dispatch to (solver_dotsocp2d.m:205-226)."""
+    if method == "acc-ADMM":
+        from .accadmm import AccADMMState
+        return AccADMMState(var, o, model, weighted=weighted)
+    if method == "PALM":
+        from .palm import PALMState
+        return PALMState(var, o, model, weighted=weighted)
+    return InPALMState(var, o, model, weighted=weighted)
+
+
 def solve_single_level(rho0, rho1, nt, opts, method="inPALM", weight=None):
     """levelN = 1 path of solver_dotsocp2d.m:190-250 / solver_dotsocp1d.m / solver_wdotsocp2d.m."""
     var, model, o = make_level(rho0, rho1, nt, opts, method, weight)
-    st = InPALMState(var, o, model, weighted=weight is not None)
+    st = make_state(var, o, model, method, weighted=weight is not None)
     st.run()
     runHist, sigma = st.finish()
     recoverOrgVar(var)

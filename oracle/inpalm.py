@@ -246,13 +246,17 @@ class InPALMState:
                 resiPri, resiDual = max(KKTResi[[0, 1]]), max(KKTResi[[2, 4]])
             self.sigma, factor = adjust_lagrangianParam(self.sigma, resiPri / resiDual, UPDATE_RULE)
             if factor != 1:
-                self.alpha = self.alpha / factor
-                self.beta = self.beta / factor
-                self.c = self.c / factor
-        if self.rescale > 0:                                                 # :319-322
+                self._apply_sigma_factor(factor)
+        if self.rescale > 0:                                                # :319-322
             self.maxFeas = np.max(KKTResi)
             self.relGap = pdGap
         return False
+
+    def _apply_sigma_factor(self, factor):
+        """solver_socp_inPALM.m:311-315"""
+        self.alpha = self.alpha / factor
+        self.beta = self.beta / factor
+        self.c = self.c / factor
 
     def run(self, n_iters=None):
         """Advance until break / maxit (or by n_iters iterations)."""

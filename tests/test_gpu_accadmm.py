@@ -1,0 +1,103 @@
+"""the accelerated ADMM loop (solver_socp_accADMM.m / solver_wsocp_accADMM.m)
+on the device against its CPU restatement (oracle/accadmm.py, PARITY UNPINNED like the inPALM oracle:
+the reference holds no fixture for it).  Same bar as the inPALM loop: every state array <= 1e-9 relative
+after K iterations with the live sigma / rescale / restart schedule, identical KKT history."""
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from oracle import driver as OD
+from oracle.accadmm import AccADMMState
+from oracle.examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, get_example_2d,
+                             get_weight_by_barrier)
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("phi", "q", "z", "alpha", "beta")
+
+
+def _relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _compare(rho0, rho1, nt, opts, K, weight=None, tol=1e-9):
+    opts = dict(opts, maxit=K)
+    weighted = weight is not None
+    ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, "acc-ADMM", weight)
+    st = AccADMMState(ovar, oo, omodel, weighted=weighted)
+    st.run()
+    o_hist, o_sigma = st.finish()
+    gvar, gmodel = D.initialize(rho0, rho1, nt)
+    if weighted:
+        gmodel.weight = np.asarray(weight, dtype=np.float64)
+    D.InitialScaling(gvar, gmodel, oo["scaling"], None, dim=2, weighted=weighted)
+    solve = D.solver_wsocp_accADMM if weighted else D.solver_socp_accADMM
+    g_hist, g_sigma = solve(gvar, oo, gmodel)
+    assert g_hist["len"] == o_hist["len"]
+    np.testing.assert_array_equal(g_hist["iter"], o_hist["iter"])
+    assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
+    np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(g_hist["pdGap"], o_hist["pdGap"], rtol=1e-6, atol=1e-14)
+    errs = {f: _relerr(getattr(gvar, f), getattr(ovar, f)) for f in FIELDS}
+    assert max(errs.values()) <= tol, errs
+    assert abs(gvar.cScale - ovar.cScale) <= 1e-12 * ovar.cScale
+    assert abs(gvar.dScale - ovar.dScale) <= 1e-12 * ovar.dScale
+    assert gvar.name == 'Accelerated ADMM'
+    assert list(gvar.time) == list(ovar.time)
+    return errs
+
+
+@pytest.mark.parametrize("n,nt,K", [(16, 8, 1), (16, 8, 2), (16, 8, 7), (32, 16, 60), (64, 32, 30), (33, 17, 25)])
+def test_trajectory_halpern(n, nt, K):
+    rho0, rho1 = get_example_2d("example1", n, n)
+    _compare(rho0, rho1, nt, dict(tol=0.0), K)
+
+
+def test_trajectory_halpern_short_restart():
+    """restart = 5: anchors are re-set every five extrapolations, also between KKT checks."""
+    rho0, rho1 = get_example_2d("example1", 24, 40)
+    _compare(rho0, rho1, 12, dict(tol=0.0, restart=5, rho=1.7), 45)
+
+
+@pytest.mark.parametrize("theta,K", [(3.0, 30), (5.0, 12)])
+def test_trajectory_nesterov_type(theta, K):
+    """theta != 2: the non-Halpern branch (solver_socp_accADMM.m:389-422) with its HatOld carry."""
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    _compare(rho0, rho1, 16, dict(tol=0.0, theta=theta, restart=8), K)
+
+
+def test_trajectory_checkstep_no_scaling():
+    rho0, rho1 = get_example_2d("example1", 16, 16)
+    _compare(rho0, rho1, 8, dict(tol=0.0, scaling=False, sigma=0.1, ifCheckStepByStep=True), 12)
+
+
+@pytest.mark.parametrize("n,nt,K", [(32, 16, 40), (33, 9, 20)])
+def test_trajectory_weighted(n, nt, K):
+    rho0, rho1 = get_example_2d("example1", n, n)
+    barrier = gene_barrier_of_circle_pillar()
+    weight = get_weight_by_barrier(n, n, nt, barrier)
+    rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    _compare(rho0, rho1, nt, dict(tol=0.0), K, weight=weight, tol=1e-8)
+
+
+def test_free_running_solve():
+    """Full solve through the driver with method = "acc-ADMM": same stop iteration as the oracle, KKT < tol,
+    mass conservation, same transport as the oracle."""
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    ovar, omodel, o_hist, o_sigma = OD.solve_single_level(rho0, rho1, 16, dict(tol=1e-4), "acc-ADMM")
+    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 16, 1, dict(tol=1e-4), "acc-ADMM")
+    assert hist["iter"][-1] == o_hist["iter"][-1]
+    assert np.max(hist["kkt"][-1][[0, 2, 5, 6]]) < 1e-4
+    np.testing.assert_allclose(hist["kkt"][-1], o_hist["kkt"][-1], rtol=1e-6, atol=1e-14)
+    rho_o, Ex_o, Ey_o = OD.recover_RhoE(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-8)
+    assert D.check_massConservation(out["rho"], 1e-2)
+    assert hist["method"] == "acc-ADMM for DOT-SOCP"
+
+
+def test_rejected_configurations():
+    rho0, rho1 = get_example_2d("example1", 16, 16)
+    var, model = D.initialize(rho0, rho1, 8)
+    D.InitialScaling(var, model, True, None, dim=2)
+    o = OD.default_opts(dict(tol=1e-3), "acc-ADMM")
+    with pytest.raises(D.capi.DotsocpError):
+        D.InPALMContext(var, o, model, nslabs=2, method="acc-ADMM")

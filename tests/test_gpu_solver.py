@@ -70,6 +70,17 @@ def test_trajectory_dot2d(n, nt, K):
     _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
 
 
+@pytest.mark.parametrize("n,nt,K", [(256, 64, 50), (257, 65, 20)])
+def test_parity_gate_config2(n, nt, K, request):
+    """SURVEY.md section 8d parity gate: BASELINE config 2 (256x256x64) and its multilevel-compatible
+    2^k+1 twin, K iterations with the live sigma / rescale schedule, all five state arrays <= 1e-9.
+    (The oracle needs about a second per iteration at this size, hence one dataflow only.)"""
+    if "unfused" in request.node.name:
+        pytest.skip("production dataflow only at this size")
+    rho0, rho1 = get_example_2d("example1", n, n)
+    _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
+
+
 def test_trajectory_dot2d_rectangular_alg2():
     rho0, rho1 = get_example_2d("example1", 24, 40)     # generator returns (nx, ny) arrays: ny = 24, nx = 40
     _compare_run(rho0, rho1, 12, dict(tol=0.0), 20, method="ALG2")
