@@ -13,4 +13,4 @@ from .mexops import (mexBFd, mexBFd1d, mexBFdConj, mexBFdConj1d, mexProjSoc, mir
 from .model import (InitialScaling, ModelHandle, VarHandle, check_massConservation, initialize,  # noqa: F401
                     initialize_slab, recover_q, recover_RhoE, recoverOrgVar)
 from .solvers import (InPALMContext, solver_dotsocp1d, solver_dotsocp2d, solver_socp_accADMM,  # noqa: F401
-                      solver_socp_inPALM, solver_wdotsocp2d, solver_wsocp_accADMM, solver_wsocp_inPALM)
+                      solver_socp_inPALM, solver_socp_PALM, solver_wdotsocp2d, solver_wsocp_accADMM, solver_wsocp_inPALM)

@@ -10,6 +10,8 @@
 //   MODE_A: same without the deferred update (beta already current): 8 (10 Nz + 2 Nq) bytes.
 //   MODE_M (2): materialise -- beta update + write z (needed by the rescale block / outputs).
 //   MODE_Z (3): z = Pi_Q(BF q_old + d - beta_in) only (z of the last iteration from the kept beta^k).
+//   MODE_P (4): PALM's extra q-step (solver_socp_PALM.m:196-200): deferred beta update as in MODE_B, then
+//               q2 = F* B* (z^k + beta^k) with the recomputed z^k -- no new projection.
 //   (line numbers: socp/dot2d/algorithms/solver_socp_inPALM.m)
 //
 // Mapping: a workgroup owns a 64 (y) x XB (x) tile of cell columns and MARCHES through a chunk
@@ -38,14 +40,15 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
     const i64 t0 = (i64)blockIdx.z * a.TC;
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
     const bool lastChunk = (t1 == g.ncl);
-    const i64 tstart = (MODE < 2 && t0 > 0) ? t0 - 1 : t0;
+    constexpr bool GATHER = (MODE < 2 || MODE == 4);
+    const i64 tstart = (GATHER && t0 > 0) ? t0 - 1 : t0;
     const i64 nxblk = gridDim.y, nyblk = gridDim.x;
 
     EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo;
     if (MODE != 0) curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
     GatherCarry gc;
     // one extra virtual step (tl == ncl, no cell) on the last chunk emits the final edge layer
-    const i64 tstop = (MODE < 2 && lastChunk) ? t1 + 1 : t1;
+    const i64 tstop = (GATHER && lastChunk) ? t1 + 1 : t1;
     for (i64 tl = tstart; tl < tstop; ++tl) {
         const bool hasCell = tl < g.ncl;
         const bool own = tl >= t0;                      // false only for the recomputed cell in front of the chunk
@@ -78,12 +81,17 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 #pragma unroll
                         for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
                     }
-                    if (MODE >= 2) {
+                    if (MODE == 2 || MODE == 3) {
 #pragma unroll
                         for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zo[j];
                     }
                 }
                 curo = nxto;
+                if (MODE == 4) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) w[j] = zo[j] + b[j];
+                    if (own && inb) a.q2[i] = c.s * (w[9] - w[0]);
+                }
             }
             cur = nxt;
             if (MODE < 2) {
@@ -98,7 +106,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 #pragma unroll
             for (int j = 0; j < 10; ++j) w[j] = 0.0;
         }
-        if (MODE < 2)   // adjoint gather for edge layer tl (gather_tile.h)
+        if (GATHER)   // adjoint gather for edge layer tl (gather_tile.h)
             gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blockIdx.y, blockIdx.x,
                             a.q2, a.sx, a.sy);
     }
@@ -134,6 +142,7 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
         case 1: hipLaunchKernelGGL((k_cone_fused<1, 4>), grid, blk, 0, st, g, c, a); break;
         case 2: hipLaunchKernelGGL((k_cone_fused<2, 4>), grid, blk, 0, st, g, c, a); break;
         case 3: hipLaunchKernelGGL((k_cone_fused<3, 4>), grid, blk, 0, st, g, c, a); break;
+        case 4: hipLaunchKernelGGL((k_cone_fused<4, 4>), grid, blk, 0, st, g, c, a); break;
         default: set_error("bad fused mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());

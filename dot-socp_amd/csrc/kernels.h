@@ -68,7 +68,7 @@ struct FusedArgs {
 };
 int fused_geometry(const Grid &g, FusedGeom &fg);
 // mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z;
-// 3: z only, from (q_old, beta_in)
+// 3: z only, from (q_old, beta_in); 4: deferred beta update + gather of (z^k + beta^k) (PALM's first q-step)
 int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
                       hipStream_t st);
 
@@ -103,6 +103,10 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
 int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, double *q_out,
                      const double *alpha_in, double *alpha_out, hipStream_t st);
+// PALM (solver_socp_PALM.m:196-200,137): first q-step without the alpha update; tmp_q = A phi in q layout
+int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                            const double *sx, const double *sy, double *q_out, const double *alpha, hipStream_t st);
+int launch_grad(const Grid &g, const LoopCoef &c, const double *phi, double *out, hipStream_t st);
 // time-slab mode: complete the adjoint sums of the last owned cell for the right neighbour (values times sf)
 int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,
                          const double *sy, double *tail_bx, double *tail_by, hipStream_t st);

@@ -536,13 +536,14 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
 int Solver::begin_method(const dotsocp_opts *o, int m, const dotsocp_acc_opts *acc) {
     if (begun) { set_error("begin() called twice"); return DOTSOCP_ESTATE; }
     if (m == DOTSOCP_METHOD_INPALM) return begin(o);
-    DS_ARG(m == DOTSOCP_METHOD_ACCADMM, "unknown method");
-    DS_ARG(prob.dim == 2, "the reference has no 1-D acc-ADMM loop");
-    DS_ARG(!multi(), "acc-ADMM runs on one slab");
+    DS_ARG(m == DOTSOCP_METHOD_ACCADMM || m == DOTSOCP_METHOD_PALM, "unknown method");
+    DS_ARG(prob.dim == 2, "the reference has PALM and acc-ADMM loops for 2-D problems only");
+    DS_ARG(!multi(), "PALM / acc-ADMM run on one slab");
+    DS_ARG(!(m == DOTSOCP_METHOD_PALM && prob.weighted), "the reference has no weighted PALM loop");
     method = m;
     int rc = begin(o);
     if (rc != 0) { method = DOTSOCP_METHOD_INPALM; return rc; }
-    return acc_begin(acc);
+    return (m == DOTSOCP_METHOD_PALM) ? palm_begin() : acc_begin(acc);
 }
 
 int Solver::begin(const dotsocp_opts *o) {
@@ -870,6 +871,8 @@ int Solver::rescale_block() {
     if (!prob.weighted) norm_d = norm_d / dScale2;      // solver_wsocp_inPALM.m has no norm_d
     // c, alpha, beta <- x * dScale2 / cScale2^2 ; q, z <- x / dScale2
     DS_CHECK(scale_state(dScale2, cScale2 * cScale2, dScale2, true));
+    if (method == DOTSOCP_METHOD_PALM)                   // solver_socp_PALM.m:191 tmp_q = A phi is scaled: scale phi
+        for (auto &s : slabs) DS_CHECK(launch_scale(s.phi, s.g.NphiAlloc, 1.0, dScale2, stream));
     dScale = dScale2 * dScale;
     cScale = cScale2 * cScale;
     sigmaScale = sigmaScale * (cScale2 / dScale2);
@@ -984,6 +987,7 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
 int Solver::step(bool *brk) {
     *brk = false;
     if (method == DOTSOCP_METHOD_ACCADMM) return acc_step(brk);
+    if (method == DOTSOCP_METHOD_PALM) return palm_step(brk);
     it += 1;
     DS_CHECK(rescale_block());
     if (overlap) {
@@ -1051,6 +1055,7 @@ int Solver::finish(dotsocp_result *res) {
         res->iters = it;
         res->hist_len = (i64)hist_iter.size();
         res->stopped = stopped ? 1 : 0;
+        if (method == DOTSOCP_METHOD_PALM) res->time_extra = phase_ms[PH_QSTEP0] * 1e-3;   // 'Step_1_Q_Step'
         if (method == DOTSOCP_METHOD_ACCADMM) {
             // Step_1_Q_Step, Step_2_Multiplier (folded into the cone pass), Step_3_1_FFT, Step_3_2_ProjSOC, KKT, Interp
             res->times[0] = (phase_ms[PH_RHS] + phase_ms[PH_POISSON]) * 1e-3;

@@ -1,0 +1,101 @@
+// Host side of the device-resident proximal ALM loop: socp/dot2d/algorithms/solver_socp_PALM.m (2-D,
+// unweighted).  PALM = inPALM with (a) z0 = BF (A phi0) + d (:136-138), (b) an extra q-step in front of the
+// phi-step (:196-200) whose result q~ feeds the phi-step and the projection (:204,209-210), and (c) a
+// rescale block that scales tmp_q = A phi instead of q (:181-191).  Rescale and KKT blocks are the inPALM
+// ones (Solver::rescale_block / kkt_block).
+//
+// Device dataflow (fused, z never stored), iteration k, entering with q^k in s.q, q~^{k-1} in s.q_old and
+// the multiplier step of iteration k-1 still pending (beta^{k-1} in memory):
+//   pass 1  k_cone_fused<4>: z^k = Pi(BF q~^{k-1} + d - beta^{k-1}) recomputed, beta^k stored,
+//           q2 = F*B*(z^k + beta^k)                                                        (:198, :224-227 of k-1)
+//   q~^k    = (A phi^k + alpha^k + q2) .* diagQInv            -> s.q_old                   (:199)
+//   phi^{k+1} from q~^k, alpha^k                                                           (:204)
+//   pass 2  k_cone_fused<0>: z^{k+1} = Pi(BF q~^k + d - beta^k), q2 = F*B*(z^{k+1} + beta^k) (:209-210,216)
+//   q^{k+1}, alpha^{k+1}                                      -> s.q                       (:215-217,221,225)
+//   beta^{k+1}: deferred to pass 1 of the next iteration (or to the KKT block)              (:222-226)
+#include <algorithm>
+#include <cmath>
+
+#include "solver.h"
+
+namespace dotsocp {
+
+int Solver::palm_begin() {
+    if (!slabs[0].q2) {
+        set_error("PALM needs the fused dataflow (unset DOTSOCP_FUSED=0)");
+        return DOTSOCP_EINVAL;
+    }
+    // :136-138  tmp_q = A phi; z = BF tmp_q + d (boundary slots keep their uploaded values, like mexBFd)
+    for (auto &s : slabs) {
+        DS_CHECK(launch_grad(s.g, lc, s.phi, s.q2, stream));
+        DS_CHECK(launch_bfd(s.g, s.z, s.q2, lc.s, lc.dF, stream));
+    }
+    deferred = false;
+    z_valid = true;
+    return 0;
+}
+
+int Solver::palm_step(bool *brk) {
+    *brk = false;
+    it += 1;
+    DS_CHECK(rescale_block());            // :142-194 (scales phi in place of tmp_q for this method)
+    // ---- first q-step :196-200 ----
+    prof_begin(PH_QSTEP0);
+    if (deferred) {
+        for (auto &s : slabs) {
+            FusedArgs a{};
+            a.q_old = s.q_old; a.q = s.q;
+            a.beta_in = s.beta; a.beta_out = s.beta2;
+            a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
+            set_pending(a);
+            DS_CHECK(launch_cone_fused(4, s.g, lc, s.fg, a, stream));
+            std::swap(s.beta, s.beta2);
+        }
+        bpend = false;
+        deferred = false;
+    } else {
+        DS_CHECK(ensure_z());             // first iteration, or right after a KKT / rescale block
+        DS_CHECK(flush_beta());
+        for (auto &s : slabs) {
+            AccArgs a{};
+            a.z_in = s.z; a.beta_in = s.beta;
+            a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
+            DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, stream));
+        }
+    }
+    for (auto &s : slabs)
+        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.q_old, s.alpha, stream));
+    prof_end(PH_QSTEP0);
+    // ---- step phi :202-205 ----
+    prof_begin(PH_RHS);
+    for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q_old, s.alpha, s.c, nullptr, nullptr, s.w0, stream));
+    prof_end(PH_RHS);
+    prof_begin(PH_POISSON);
+    DS_CHECK(poisson_all());
+    prof_end(PH_POISSON);
+    // ---- step z :207-211 (+ the adjoint sums of :216) ----
+    prof_begin(PH_FUSED_A);
+    for (auto &s : slabs) {
+        FusedArgs a{};
+        a.q = s.q_old;
+        a.beta_in = s.beta;
+        a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
+        DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, stream));
+    }
+    prof_end(PH_FUSED_A);
+    z_valid = false;
+    z_prev_ok = false;
+    // ---- second q-step + alpha :213-218,221,225 ----
+    prof_begin(PH_QSTEP);
+    for (auto &s : slabs)
+        DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, nullptr, nullptr, s.q, s.alpha, stream));
+    prof_end(PH_QSTEP);
+    deferred = true;                       // beta^{k+1}: :222-226, executed by the next pass over beta
+    const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                 // :231
+    const bool timed_out = elapsed() > time_limit;
+    if (opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out)       // :232
+        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
+    return 0;
+}
+
+}  // namespace dotsocp

@@ -73,11 +73,12 @@ struct WSum {
     __device__ __forceinline__ double operator()(int j, i64 cell) const { return z[j * Nz + cell] + b[j * Nz + cell]; }
 };
 
-template <bool WEIGHTED, bool ACC = false>
+// VAR 0: inPALM / ALG2; 1: acc-ADMM (alpha_out = (alpha_in + tmp) - w q); 2: PALM's first q-step (alpha untouched)
+template <bool WEIGHTED, int VAR = 0>
 __device__ __forceinline__ void q_update(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
                                          const double *__restrict__ weight, double *__restrict__ q,
                                          double *alpha, const double *alpha_in = nullptr) {
-    const double a = ACC ? alpha_in[k] : alpha[k];
+    const double a = (VAR == 1) ? alpha_in[k] : alpha[k];
     double qn, r;
     if (WEIGHTED) {
         const double w = weight[k];
@@ -89,7 +90,8 @@ __device__ __forceinline__ void q_update(const LoopCoef &c, double tmp, double q
         r = tmp - qn;
     }
     q[k] = qn;
-    if (ACC) {
+    if (VAR == 2) return;
+    if (VAR == 1) {
         // alpha + tmp_q - w.*q, left to right (solver_socp_accADMM.m:237, solver_wsocp_accADMM.m:243)
         const double t = a + tmp;
         alpha[k] = WEIGHTED ? t - weight[k] * qn : t - qn;
@@ -164,7 +166,7 @@ int launch_qstep(const Grid &g, const LoopCoef &c, const double *phi, const doub
 
 // q-step on the adjoint sums produced by the fused cone kernel (fused.hip): q2 already holds
 // sf * sum for tile-interior edges and the own tile's raw partial for tile-boundary edges.
-template <bool WEIGHTED, int SEG, bool ACC = false>
+template <bool WEIGHTED, int SEG, int VAR = 0>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef c, FusedGeom fg,
                                                                  const double *__restrict__ phi,
                                                                  const double *__restrict__ q2v,
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
         if (tl < g.ncl) {
             double tmp = (-c.at) * p0;
             tmp += c.at * phi[node + g.plane];
-            q_update<WEIGHTED, ACC>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha, alpha_in);
+            q_update<WEIGHTED, VAR>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha, alpha_in);
         }
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
         const double dc = tbnd ? c.c2 : c.c1;
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
             if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];
-            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
+            q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
         if (y < g.ny - 1) {
             const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
@@ -208,13 +210,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
             if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
-            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
+            q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
     } else if (SEG == 0) {
         if (y >= g.ny || x >= g.nx) return;
         double tmp = (-c.at) * phi[node];
         tmp += c.at * phi[node + g.plane];
-        q_update<WEIGHTED, ACC>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha, alpha_in);
+        q_update<WEIGHTED, VAR>(c, tmp, q2v[node], c.c1, c.dinv1, node, weight, q, alpha, alpha_in);
     } else {
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
         const double dc = tbnd ? c.c2 : c.c1;
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
             if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];      // left slab's part, already times sf
-            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
+            q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         } else {
             if (y >= g.ny - 1 || x >= g.nx) return;
             const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
             if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
-            q_update<WEIGHTED, ACC>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
+            q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
     }
 }
@@ -266,11 +268,53 @@ int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, cons
     dim3 blk(TILE_Y, TILE_X);
     const double *none = nullptr;
     if (weight)
-        hipLaunchKernelGGL((k_qstep_fused<true, 3, true>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
+        hipLaunchKernelGGL((k_qstep_fused<true, 3, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
                            weight, none, none, q_out, alpha_out, alpha_in);
     else
-        hipLaunchKernelGGL((k_qstep_fused<false, 3, true>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
+        hipLaunchKernelGGL((k_qstep_fused<false, 3, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
                            weight, none, none, q_out, alpha_out, alpha_in);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// PALM's first q-step (solver_socp_PALM.m:196-200): q_out = (A phi + alpha + q2) .* diagQInv, alpha untouched
+int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                            const double *sx, const double *sy, double *q_out, const double *alpha, hipStream_t st) {
+    const double *none = nullptr;
+    hipLaunchKernelGGL((k_qstep_fused<false, 3, 2>), tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, fg, phi, q2,
+                       sx, sy, none, none, none, q_out, const_cast<double *>(alpha), none);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// tmp_q = A phi in q layout (solver_socp_PALM.m:137): forward differences times D/h, like the q-step
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_grad(Grid g, LoopCoef c, const double *__restrict__ phi,
+                                                          double *__restrict__ out) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    const i64 tl = blockIdx.z;
+    if (y >= g.ny || x >= g.nx) return;
+    const i64 node = y + g.ny * (x + g.nx * tl);
+    const double p0 = phi[node];
+    if (tl < g.ncl) {
+        double tmp = (-c.at) * p0;
+        tmp += c.at * phi[node + g.plane];
+        out[node] = tmp;
+    }
+    if (x < g.nx - 1) {
+        double tmp = (-c.ax) * p0;
+        tmp += c.ax * phi[node + g.ny];
+        out[g.offBx + g.bxLayer * tl + y + g.ny * x] = tmp;
+    }
+    if (y < g.ny - 1) {
+        double tmp = (-c.ay) * p0;
+        tmp += c.ay * phi[node + 1];
+        out[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x] = tmp;
+    }
+}
+
+int launch_grad(const Grid &g, const LoopCoef &c, const double *phi, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_grad, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, phi, out);
     DS_HIP(hipGetLastError());
     return 0;
 }

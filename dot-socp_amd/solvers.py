@@ -26,6 +26,8 @@ ACC_TIME_NAMES = ['Step_1_Q_Step', 'Step_2_Multiplier', 'Step_3_1_FFT', 'Step_3_
                   'Total_Time', 'Iters']
 WACC_TIME_NAMES = ['Step_1_Q_Step', 'Step_2_Multiplier', 'Step_3_1_FFT', 'Step_3_2_ProjSOC', 'Step_4_Interp', 'KKT',
                    'Total_Time', 'Iters']
+PALM_TIME_NAMES = ['Step_1_Q_Step', 'Step_2_1_FFT', 'Step_2_2_ProjSOC', 'Step_3_Q_Step', 'Step_4_Multiplier', 'KKT',
+                   'Total_Time', 'Iters']      # solver_socp_PALM.m:351-352
 METHODS = {"inPALM": capi.METHOD_INPALM, "ALG2": capi.METHOD_INPALM, "PALM": capi.METHOD_PALM,
            "acc-ADMM": capi.METHOD_ACCADMM}
 
@@ -126,7 +128,7 @@ class InPALMContext:
         res = capi.Result()
         capi.check(L.dotsocp_finish(self._ctx, ctypes.byref(res)))
         var = self.var
-        var.name = 'Accelerated ADMM' if self.method == "acc-ADMM" else 'Inexact Proximal ALM'
+        var.name = {"acc-ADMM": 'Accelerated ADMM', "PALM": 'Proximal ALM'}.get(self.method, 'Inexact Proximal ALM')
         if download:
             var.phi = self.download(capi.F_PHI, var.phi)
             var.q = self.download(capi.F_Q, var.q)
@@ -138,6 +140,8 @@ class InPALMContext:
             tm = dict(Step_1_Q_Step=t[2], Step_2_Multiplier=t[3], Step_3_1_FFT=t[0], Step_3_2_ProjSOC=t[1], KKT=t[4],
                       Interp=res.time_extra, Step_4_Interp=res.time_extra, Total_Time=t[5], Iters=t[6])
             var.time = {k: tm[k] for k in (WACC_TIME_NAMES if self.weighted else ACC_TIME_NAMES)}
+        elif self.method == "PALM":
+            var.time = dict(zip(PALM_TIME_NAMES, [res.time_extra] + t))
         else:
             var.time = dict(zip(TIME_NAMES, t))
         var.cScale, var.dScale = res.cScale, res.dScale
@@ -180,6 +184,16 @@ def solver_wsocp_inPALM(var, opts, model, device=0, nslabs=1):
         ctx.close()
 
 
+def solver_socp_PALM(var, opts, model, device=0):
+    """[runHist, sigma] = solver_socp_PALM(var, opts, model)   socp/dot2d/algorithms/solver_socp_PALM.m:1"""
+    ctx = InPALMContext(var, opts, model, weighted=False, device=device, method="PALM")
+    try:
+        ctx.run(-1)
+        return ctx.finish()
+    finally:
+        ctx.close()
+
+
 def solver_socp_accADMM(var, opts, model, device=0):
     """[runHist, sigma] = solver_socp_accADMM(var, opts, model)   socp/dot2d/algorithms/solver_socp_accADMM.m:1
     opts: sigma, maxit, tol, ifCheckStepByStep (+ restart, rho, theta, checkPrimDualFeas, time_limit, scaling)."""
@@ -206,14 +220,16 @@ def solver_wsocp_accADMM(var, opts, model, device=0):
 # --------------------------------------------------------------------------------------
 def _driver_opts(opts, method, weighted, dim=2):
     """solver_dotsocp2d.m:76-151 / solver_dotsocp1d.m / solver_wdotsocp2d.m:85-162."""
-    if method not in ("inPALM", "ALG2") and not (method == "acc-ADMM" and dim == 2):
+    ok = method in ("inPALM", "ALG2") or (method == "acc-ADMM" and dim == 2) or (
+        method == "PALM" and dim == 2 and not weighted)                   # solver_dotsocp2d.m:205-226
+    if not ok:
         raise ValueError("Invalid input at position 6 (Solving method)")
     o = dict(opts) if isinstance(opts, dict) else dict(vars(opts))
     o.setdefault("ifCheckStepByStep", False)
     o.setdefault("scaling", True)
     o.setdefault("maxit", 10000 if weighted else 3000)
     if method != "acc-ADMM":
-        o["tau"] = 1.9 if method == "inPALM" else 1.0
+        o["tau"] = 1.0 if method == "ALG2" else 1.9                       # :133-137
     o.setdefault("sigma", 1.0)
     o.setdefault("time_limit", 3600)
     return o
@@ -257,6 +273,8 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
         model.weight = ws[0]
     if method == "acc-ADMM":                                             # :224-225
         solve = solver_wsocp_accADMM if weighted else solver_socp_accADMM
+    elif method == "PALM":                                               # :205-206
+        solve = solver_socp_PALM
     else:
         solve = solver_wsocp_inPALM if weighted else solver_socp_inPALM
     timeML, runHistML, runHist, last = [], None, None, None

@@ -1,0 +1,70 @@
+"""the proximal ALM loop (solver_socp_PALM.m) on the device against its CPU
+restatement (oracle/palm.py, PARITY UNPINNED: no fixture in the reference).  Same bar as inPALM."""
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from oracle import driver as OD
+from oracle.examples import get_example_2d
+from oracle.palm import PALMState
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("phi", "q", "z", "alpha", "beta")
+
+
+def _relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _compare(rho0, rho1, nt, opts, K, tol=1e-9):
+    opts = dict(opts, maxit=K)
+    ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, "PALM")
+    st = PALMState(ovar, oo, omodel)
+    st.run()
+    o_hist, o_sigma = st.finish()
+    gvar, gmodel = D.initialize(rho0, rho1, nt)
+    D.InitialScaling(gvar, gmodel, oo["scaling"], None, dim=2)
+    g_hist, g_sigma = D.solver_socp_PALM(gvar, oo, gmodel)
+    assert g_hist["len"] == o_hist["len"]
+    np.testing.assert_array_equal(g_hist["iter"], o_hist["iter"])
+    assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
+    np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(g_hist["pdGap"], o_hist["pdGap"], rtol=1e-6, atol=1e-14)
+    errs = {f: _relerr(getattr(gvar, f), getattr(ovar, f)) for f in FIELDS}
+    assert max(errs.values()) <= tol, errs
+    assert abs(gvar.cScale - ovar.cScale) <= 1e-12 * ovar.cScale
+    assert abs(gvar.dScale - ovar.dScale) <= 1e-12 * ovar.dScale
+    assert gvar.name == 'Proximal ALM'
+    assert list(gvar.time) == list(ovar.time)
+    return errs
+
+
+@pytest.mark.parametrize("n,nt,K", [(16, 8, 1), (16, 8, 2), (16, 8, 5), (32, 16, 60), (64, 32, 30), (33, 17, 25)])
+def test_trajectory(n, nt, K):
+    rho0, rho1 = get_example_2d("example1", n, n)
+    _compare(rho0, rho1, nt, dict(tol=0.0), K)
+
+
+def test_trajectory_rectangular_checkstep():
+    rho0, rho1 = get_example_2d("example1", 24, 40)
+    _compare(rho0, rho1, 12, dict(tol=0.0, scaling=False, sigma=0.1, ifCheckStepByStep=True), 12)
+
+
+def test_free_running_solve():
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    ovar, omodel, o_hist, o_sigma = OD.solve_single_level(rho0, rho1, 16, dict(tol=1e-4), "PALM")
+    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 16, 1, dict(tol=1e-4), "PALM")
+    assert hist["iter"][-1] == o_hist["iter"][-1]
+    assert np.max(hist["kkt"][-1][[0, 2, 5, 6]]) < 1e-4
+    np.testing.assert_allclose(hist["kkt"][-1], o_hist["kkt"][-1], rtol=1e-6, atol=1e-14)
+    rho_o, Ex_o, Ey_o = OD.recover_RhoE(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-8)
+    assert D.check_massConservation(out["rho"], 1e-2)
+    assert hist["method"] == "PALM for DOT-SOCP"
+
+
+def test_rejected_configurations():
+    from oracle.examples import get_example_1d
+    rho0, rho1 = get_example_1d("gaussian", 64)
+    with pytest.raises(ValueError):
+        D.solver_dotsocp1d(rho0, rho1, 16, 1, dict(tol=1e-3), "PALM")
