@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NY", "NX", "NT"),
                     help="override the grid (default 1024 1024 128)")
     ap.add_argument("--workload", choices=["dot2d", "wdot2d", "dot1d"], default="dot2d")
+    ap.add_argument("--method", choices=["inPALM", "ALG2", "PALM", "acc-ADMM"], default="inPALM",
+                    help="loop variant (diagnostic; BASELINE.json's metric is quoted on inPALM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nslabs", type=int, default=1,
                     help="diagnostics: run the time-slab algorithm with this many slabs inside ONE process / GPU")
@@ -151,7 +153,7 @@ def main():
         if args.workload != "dot2d":
             raise SystemExit("multi-GPU bench runs the dot2d workload")
 
-    opts = dict(tau=1.9, sigma=1.0, tol=0.0, maxit=args.warmup + args.steps, scaling=True,
+    opts = dict(tau=1.0 if args.method == "ALG2" else 1.9, sigma=1.0, tol=0.0, maxit=args.warmup + args.steps, scaling=True,
                 ifCheckStepByStep=False, time_limit=1e9)
     if world == 1:
         var, model, rho0, rho1, weight = build_problem(D, args.workload, ny, nx, nt)
@@ -162,7 +164,7 @@ def main():
         var, model = D.initialize_slab(rho0, rho1, nt, t0s, t1s)
         D.InitialScaling(var, model, True, None, dim=2)
     ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False, rccl=rccl,
-                          nslabs=args.nslabs)
+                          nslabs=args.nslabs, method=args.method)
 
     def fence():
         ctx.synchronize()
@@ -186,7 +188,8 @@ def main():
         dt = float(tmax.item())
     hist, sigma = ctx.finish(download=False)
     times = {k: ctx.kernel_time(k) for k in ("rhs", "poisson", "cone_fused_a", "cone_fused_b", "cone_proj",
-                                             "qstep", "beta", "materialise", "kkt", "comm")}
+                                             "qstep", "beta", "materialise", "kkt", "comm", "interp", "acc_cone",
+                                             "acc_gather", "qstep_first")}
     ctx.close()
 
     # per-launch sizes of THIS rank's slab (the whole grid at N = 1)
@@ -198,7 +201,14 @@ def main():
     # Dominant kernel: the fused cone kernel in its steady-state mode (deferred multiplier update +
     # cone projection + adjoint gather).  Algorithmic bytes per launch:
     # beta in + beta out (20 Nz) + q^{k-1}, q^k in (2 Nq) + adjoint sums out (Nq), fp64.
-    if times["cone_fused_b"][1] > 0:
+    if args.method == "acc-ADMM":
+        # multiplier + z-step + Halpern step of z, beta + next adjoint sums: z, beta, anchors in, z, beta out
+        kname, (proj_ms, proj_n) = "k_acc_cone<1,4> (multiplier + projection + Halpern + gather)", times["acc_cone"]
+        alg_bytes = 8.0 * (60 * Nz + 2 * Nq)
+    elif args.method == "PALM":
+        kname, (proj_ms, proj_n) = "k_cone_fused<0,4> (cone projection + adjoint gather)", times["cone_fused_a"]
+        alg_bytes = 8.0 * (10 * Nz + 2 * Nq)
+    elif times["cone_fused_b"][1] > 0:
         kname, (proj_ms, proj_n) = "k_cone_fused<1,4> (beta update + cone projection + adjoint gather)", times["cone_fused_b"]
         alg_bytes = 8.0 * (20 * Nz + 3 * Nq)
     else:                                     # DOTSOCP_FUSED=0: plain projection kernel, beta in + q in + z out
@@ -210,7 +220,7 @@ def main():
     if os.path.exists(tf):
         try:
             rec = json.load(open(tf))
-            if rec.get("grid") == [ny, nx, nt]:
+            if rec.get("grid") == [ny, nx, nt] and args.method in ("inPALM", "ALG2"):
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -227,7 +237,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {ny}x{nx}x{nt} Gaussian-to-Gaussian (Example 5.1), inPALM tau=1.9, levelN=1",
+        "config": {"workload": f"{args.workload} {ny}x{nx}x{nt} Gaussian-to-Gaussian (Example 5.1), " + {
+                       "inPALM": "inPALM tau=1.9", "ALG2": "ALG2 tau=1.0", "PALM": "PALM tau=1.9",
+                       "acc-ADMM": "acc-ADMM (Halpern, rho=2, restart=100)"}[args.method] + ", levelN=1",
                    "grid": [ny, nx, nt], "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
                    "parallelism": "1 GPU" if world == 1 else f"{world} time slabs"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
@@ -237,7 +249,7 @@ def main():
         "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
     }
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.method == "inPALM":
             out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -7,9 +7,11 @@
  *        phi, q, alpha, z, beta, c, [weight], nx, [ny], nt, D, E, cScale, dScale, normc, normd
  * opts : the options struct of solver_socp_inPALM.m:20-37,64-68 (tau, sigma, maxit, tol,
  *        ifCheckStepByStep required; checkPrimDualFeas, time_limit, scaling optional; device, ngpu
- *        optional extensions)
+ *        optional extensions).  opts.method (extension, set by the .m wrappers): 'inPALM' (default),
+ *        'PALM' (solver_socp_PALM.m) or 'accADMM' (solver_socp_accADMM.m / solver_wsocp_accADMM.m,
+ *        which also reads restart, rho, theta, :12-28, and no tau)
  * out  : struct phi, q, z, alpha (= sigma*alpha), beta (= sigma*beta), sigma, cScale, dScale,
- *        times (1x7), kkt (len x 7), time, iter, pdGap (len x 1)      (:329-357)
+ *        times (1x7), time_extra, kkt (len x 7), time, iter, pdGap (len x 1)      (:329-357)
  *
  * The .m wrapper copies `out` back into the handle objects, so demo_dot*.m run unmodified. */
 #include <string.h>
@@ -57,7 +59,20 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     p.normd = opt(S, "normd", 0.0);
     dotsocp_opts o;
     memset(&o, 0, sizeof o);
-    o.tau = mxGetScalar(need(O, "tau"));
+    int method = DOTSOCP_METHOD_INPALM;
+    const mxArray *mf = mxGetField(O, 0, "method");
+    if (mf && !mxIsEmpty(mf)) {
+        char name[16];
+        if (mxGetString(mf, name, sizeof name) != 0) mexErrMsgIdAndTxt(ID, "opts.method must be a short char array");
+        if (strcmp(name, "PALM") == 0) method = DOTSOCP_METHOD_PALM;
+        else if (strcmp(name, "accADMM") == 0) method = DOTSOCP_METHOD_ACCADMM;
+        else if (strcmp(name, "inPALM") != 0) mexErrMsgIdAndTxt(ID, "unknown opts.method '%s'", name);
+    }
+    dotsocp_acc_opts acc;
+    acc.restart = (dotsocp_i64)opt(O, "restart", 0);      /* 0: reference defaults (solver_socp_accADMM.m:12-28) */
+    acc.rho = opt(O, "rho", 0);
+    acc.theta = opt(O, "theta", 0);
+    o.tau = (method == DOTSOCP_METHOD_ACCADMM) ? 1.0 : mxGetScalar(need(O, "tau"));
     o.sigma = mxGetScalar(need(O, "sigma"));
     o.maxit = (dotsocp_i64)mxGetScalar(need(O, "maxit"));
     o.tol = mxGetScalar(need(O, "tol"));
@@ -76,7 +91,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     for (int i = 0; i < 6 && rc == 0; ++i) rc = dotsocp_upload(ctx, fields[i], ds_real(need(S, names[i]), ID, names[i]));
     if (rc == 0 && p.weighted) rc = dotsocp_upload(ctx, DOTSOCP_F_WEIGHT, ds_real(wf, ID, "weight"));
     dotsocp_result res;
-    if (rc == 0) rc = dotsocp_begin(ctx, &o);
+    if (rc == 0) rc = dotsocp_begin_method(ctx, &o, method, &acc);
     if (rc == 0) rc = dotsocp_run(ctx, -1, NULL);
     if (rc == 0) rc = dotsocp_finish(ctx, &res);
     if (rc != 0) {
@@ -84,8 +99,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());
     }
     static const char *outf[] = {"phi", "q", "z", "alpha", "beta", "sigma", "cScale", "dScale", "times",
-                                 "kkt", "time", "iter", "pdGap"};
-    mxArray *out = mxCreateStructMatrix(1, 1, 13, outf);
+                                 "kkt", "time", "iter", "pdGap", "time_extra"};
+    mxArray *out = mxCreateStructMatrix(1, 1, 14, outf);
+    mxSetField(out, 0, "time_extra", mxCreateDoubleScalar(res.time_extra));
     mxSetField(out, 0, "phi", take(ctx, DOTSOCP_F_PHI, need(S, "phi")));
     mxSetField(out, 0, "q", take(ctx, DOTSOCP_F_Q, need(S, "q")));
     mxSetField(out, 0, "z", take(ctx, DOTSOCP_F_Z, need(S, "z")));
