@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace dotsocp {
@@ -431,6 +432,170 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup-wide flavour: ALL threads of the workgroup share ALL staged rows (butterfly groups are
+// dealt round-robin to the T threads, __syncthreads() between register groups).  Twice the waves per
+// staged row of the per-wave flavour above at the same LDS footprint -- the footprint, not registers,
+// caps the resident workgroups per CU, so this doubles the waves that overlap VALU, LDS and HBM phases.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fft_rows_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T,
+                                            const double2 *__restrict__ tw) {
+    const int nst = (lg + 3) >> 2;
+    const int baseBits = lg / nst, extra = lg % nst;
+    int sl = lg;
+    for (int st = 0; st < nst; ++st) {
+        const int lr = baseBits + (st < extra ? 1 : 0);
+        const int lpr = lg - lr;
+        const int total = 1 << (lrows + lpr);
+        for (int b = t; b < total; b += T) {
+            double2 *r = rows + (b >> lpr) * rowStride;
+            const int bidx = b & ((1 << lpr) - 1);
+            switch (lr) {
+                case 4: dif_group<4>(r, sl, bidx, lg, tw); break;
+                case 3: dif_group<3>(r, sl, bidx, lg, tw); break;
+                case 2: dif_group<2>(r, sl, bidx, lg, tw); break;
+                default: dif_group<1>(r, sl, bidx, lg, tw); break;
+            }
+        }
+        sl -= lr;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void idct_combine_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T,
+                                                const double2 *__restrict__ ww) {
+    const int n = 1 << lg, lh = lg - 1;
+    const int total = 1 << (lrows + lh);
+    for (int b = t; b < total; b += T) {
+        double2 *r = rows + (b >> lh) * rowStride;
+        const int k = (b & ((1 << lh) - 1)) + 1;          // 1 .. n/2
+        const int m = n - k;
+        const double2 xk = r[padi(k)], xm = r[padi(m)];
+        const double2 wk = ww[k], wm = ww[m];
+        const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
+        const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
+        r[padi(k)] = make_double2(gar - gbi, gai + gbr);
+        if (m != k) {
+            const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
+            const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
+            r[padi(m)] = make_double2(har - hbi, hai + hbr);
+        }
+    }
+    if (t < (1 << lrows)) {
+        double2 *r = rows + t * rowStride;
+        const double w0 = ww[0].x;
+        r[0] = make_double2(w0 * r[0].x, w0 * r[0].y);
+    }
+    __syncthreads();
+}
+
+#define DCT_WG_THREADS 512
+// Axis 0, workgroup-wide: the workgroup stages 2^lrows complex rows (pairs of consecutive lines).
+template <bool INVERSE>
+__global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double *__restrict__ src,
+                                                                     double *__restrict__ dst, i64 nLines, int lg,
+                                                                     int lrows, const double2 *__restrict__ tw,
+                                                                     const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    const int n = 1 << lg, lh = lg - 1;
+    const int rowStride = row_stride(n);
+    const int tid = threadIdx.x;
+    const i64 pair0 = (i64)blockIdx.x << lrows;
+    const int total = 1 << (lrows + lh);
+    for (int b0 = tid; b0 < total; b0 += DCT_WG_THREADS * DCT_BATCH) {
+        double2 A[DCT_BATCH], B[DCT_BATCH];
+#pragma unroll
+        for (int u = 0; u < DCT_BATCH; ++u) {
+            const int b = b0 + DCT_WG_THREADS * u;
+            const int rr = b >> lh, j = b & ((1 << lh) - 1);
+            const i64 La = 2 * (pair0 + rr);
+            A[u] = make_double2(0.0, 0.0);
+            B[u] = A[u];
+            if (b < total && La < nLines) A[u] = *(const double2 *)(src + La * n + 2 * j);
+            if (b < total && La + 1 < nLines) B[u] = *(const double2 *)(src + (La + 1) * n + 2 * j);
+        }
+#pragma unroll
+        for (int u = 0; u < DCT_BATCH; ++u) {
+            const int b = b0 + DCT_WG_THREADS * u;
+            if (b >= total) break;
+            const int rr = b >> lh, j = b & ((1 << lh) - 1);
+            double2 *r = lds + rr * rowStride;
+            if (!INVERSE) {
+                r[padi(j)] = make_double2(A[u].x, B[u].x);
+                r[padi(n - 1 - j)] = make_double2(A[u].y, B[u].y);
+            } else {
+                r[padi(2 * j)] = make_double2(A[u].x, B[u].x);
+                r[padi(2 * j + 1)] = make_double2(A[u].y, B[u].y);
+            }
+        }
+    }
+    __syncthreads();
+    if (INVERSE) idct_combine_wg(lds, lrows, lg, rowStride, tid, DCT_WG_THREADS, ww);
+    fft_rows_wg(lds, lrows, lg, rowStride, tid, DCT_WG_THREADS, tw);
+    for (int b = tid; b < total; b += DCT_WG_THREADS) {
+        const int rr = b >> lh, j = b & ((1 << lh) - 1);
+        const i64 La = 2 * (pair0 + rr);
+        const double2 *r = lds + rr * rowStride;
+        double2 A, B;
+        if (!INVERSE) {
+            const double2 p0 = dct_post(r, 2 * j, n, lg, ww), p1 = dct_post(r, 2 * j + 1, n, lg, ww);
+            A = make_double2(p0.x, p1.x);
+            B = make_double2(p0.y, p1.y);
+        } else {
+            const double2 v0 = r[padi(bitrev(j, lg))], v1 = r[padi(bitrev(n - 1 - j, lg))];
+            A = make_double2(v0.x, v1.x);
+            B = make_double2(v0.y, v1.y);
+        }
+        if (La < nLines) *(double2 *)(dst + La * n + 2 * j) = A;
+        if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * n + 2 * j) = B;
+    }
+}
+
+// Strided axes, workgroup-wide (forward / inverse only; 16-byte accesses: both lines of a pair per access).
+template <int MODE /*0 fwd, 1 inv*/>
+__global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_strided_wg(const double *__restrict__ src,
+                                                                       double *__restrict__ dst, LineMap map, int lg,
+                                                                       int lp, const double2 *__restrict__ tw,
+                                                                       const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    const int n = 1 << lg;
+    const int rowStride = row_stride(n);
+    const int npairs = 1 << lp;
+    const int tid = threadIdx.x;
+    const i64 L0 = (i64)blockIdx.x << (lp + 1);
+    const int r = tid & (npairs - 1);
+    const i64 L = L0 + 2 * r;
+    const bool ok = L < map.nLines;
+    const i64 lb = ok ? map.base(L) : 0;
+    const int kstep = DCT_WG_THREADS >> lp;
+    for (int k0 = tid >> lp; k0 < n; k0 += kstep * DCT_BATCH) {
+        double2 gv[DCT_BATCH];
+#pragma unroll
+        for (int u = 0; u < DCT_BATCH; ++u) {
+            const int k = k0 + u * kstep;
+            gv[u] = (ok && k < n) ? *(const double2 *)(src + lb + (i64)k * map.nin) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < DCT_BATCH; ++u) {
+            const int k = k0 + u * kstep;
+            if (k < n) lds[r * rowStride + padi(MODE == 1 ? k : makhoul(k, n))] = gv[u];
+        }
+    }
+    __syncthreads();
+    if (MODE == 1) idct_combine_wg(lds, lp, lg, rowStride, tid, DCT_WG_THREADS, ww);
+    fft_rows_wg(lds, lp, lg, rowStride, tid, DCT_WG_THREADS, tw);
+    if (ok) {
+        const double2 *rr = lds + r * rowStride;
+        for (int k = tid >> lp; k < n; k += kstep) {
+            double2 v;
+            if (MODE == 0) v = dct_post(rr, k, n, lg, ww);
+            else v = rr[padi(bitrev(makhoul(k, n), lg))];
+            *(double2 *)(dst + lb + (i64)k * map.nin) = v;
+        }
+    }
+}
+
 // Dense fallback (any length n): out_k = sum_j M[j*n + k] in_j.  A workgroup stages TL lines in
 // LDS and produces the outputs k in [blockIdx.y * KC, +KC) of each of them.
 //   axis 0 (lines contiguous):  thread <-> k, accumulating all TL lines per load of M (M is read once
@@ -516,6 +681,11 @@ static void allow_big_lds(K kernel) {
 
 bool dct_plan_is_pow2(const DctPlan *p) { return p->log2n > 0; }
 
+static bool dct_wg_enabled() {
+    static const bool on = !(getenv("DOTSOCP_DCT_WG") && atoi(getenv("DOTSOCP_DCT_WG")) == 0);
+    return on;
+}
+
 static int launch_strided(int mode, const DctPlan *p, const double *src, double *dst, const LineMap &map,
                           const SolveArgs &sa, hipStream_t st) {
     const int n = (int)p->n, lg = p->log2n;
@@ -525,6 +695,18 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (dct_wg_enabled() && vec && mode != 2 && ((i64)n << lp) >= 2 * DCT_WG_THREADS) {
+        static bool once_wg = false;
+        if (!once_wg) { allow_big_lds(k_dct_strided_wg<0>); allow_big_lds(k_dct_strided_wg<1>); once_wg = true; }
+        if (mode == 0)
+            hipLaunchKernelGGL((k_dct_strided_wg<0>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
+                               p->tw, p->ww);
+        else
+            hipLaunchKernelGGL((k_dct_strided_wg<1>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
+                               p->tw, p->ww);
+        DS_HIP(hipGetLastError());
+        return 0;
+    }
 #define LAUNCH_STRIDED(M, V)                                                                                   \
     do {                                                                                                       \
         static bool once = false;                                                                              \
@@ -589,7 +771,24 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         const i64 linesPerBlock = (i64)(2 * DCT_WAVES) << lrw;
         const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
         static bool once = false;
-        if (!once) { allow_big_lds(k_dct_axis0<false>); allow_big_lds(k_dct_axis0<true>); once = true; }
+        if (!once) {
+            allow_big_lds(k_dct_axis0<false>); allow_big_lds(k_dct_axis0<true>);
+            allow_big_lds(k_dct_axis0_wg<false>); allow_big_lds(k_dct_axis0_wg<true>);
+            once = true;
+        }
+        if (dct_wg_enabled() && ((n / 2) << lp) >= 2 * DCT_WG_THREADS) {
+            // same rows per workgroup (4 << lrw complex rows), twice the threads, shared by all of them
+            const int lrows = lrw + 2;
+            const unsigned wblocks = (unsigned)((((map.nLines + 1) / 2) + ((i64)1 << lrows) - 1) >> lrows);
+            if (inverse)
+                hipLaunchKernelGGL(k_dct_axis0_wg<true>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
+                                   lg, lrows, p->tw, p->ww);
+            else
+                hipLaunchKernelGGL(k_dct_axis0_wg<false>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
+                                   lg, lrows, p->tw, p->ww);
+            DS_HIP(hipGetLastError());
+            return 0;
+        }
         if (inverse)
             hipLaunchKernelGGL(k_dct_axis0<true>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
                                p->tw, p->ww);

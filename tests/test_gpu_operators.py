@@ -104,6 +104,14 @@ def test_dctn_matches_scipy(shape):
     np.testing.assert_allclose(D.mirt_idctn(D.mirt_dctn(a)), a, atol=tol)
 
 
+@pytest.mark.parametrize("shape", [(1024, 1024, 16), (512, 2048, 8), (256, 4096, 8), (128, 8192, 8), (1024, 1023, 9)])
+def test_dctn_many_lines(shape):
+    """Many lines per axis (every workgroup of the chip busy several times over), odd line counts, dense x / t axes."""
+    a = np.asfortranarray(rng.standard_normal(shape))
+    np.testing.assert_allclose(D.mirt_dctn(a), sfft.dctn(a, norm="ortho"), atol=2e-12)
+    np.testing.assert_allclose(D.mirt_idctn(a), sfft.idctn(a, norm="ortho"), atol=2e-12)
+
+
 @pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32)])
 def test_oper_poisson(ny, nx, nt):
     Dsc = 0.37
