@@ -105,6 +105,15 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 
 __device__ __forceinline__ int bitrev(int k, int lg) { return (int)(__brev((unsigned)k) >> (32 - lg)); }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  On the strided axes two
+// neighbouring tiles share every 128-byte line they touch (a tile row is 64 bytes wide for n = 1024), so the
+// tile index is permuted such that neighbouring tiles run on the SAME XCD back to back: the second one
+// hits in L2 instead of fetching the line from HBM a second time.  Bijection on [0, nb).
+__device__ __forceinline__ i64 xcd_tile(unsigned b, unsigned nb) {
+    const unsigned full = nb >> 3, rem = nb & 7u, r = b & 7u, q = b >> 3;
+    return (i64)r * full + (r < rem ? r : rem) + q;
+}
+
 #define DCT_THREADS 256
 #define DCT_WAVES 4
 #define DCT_BATCH 8   // global loads in flight per lane before the first dependent LDS write
@@ -336,7 +345,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
     const int rowStride = row_stride(n);
     const int npairs = 1 << lp;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const i64 L0 = (i64)blockIdx.x << (lp + 1);
+    const i64 L0 = xcd_tile(blockIdx.x, gridDim.x) << (lp + 1);
     // rows of this wave: npairs / 4 each (all rows go to the first waves when npairs < 4)
     const int lrw = (lp >= 2) ? lp - 2 : 0;
     const bool waveActive = (wave << lrw) < npairs;
@@ -553,8 +562,8 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
 }
 
 // Strided axes, workgroup-wide (forward / inverse only; 16-byte accesses: both lines of a pair per access).
-template <int MODE /*0 fwd, 1 inv*/>
-__global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_strided_wg(const double *__restrict__ src,
+template <int MODE /*0 fwd, 1 inv*/, int T>
+__global__ void __launch_bounds__(T, 4) k_dct_strided_wg(const double *__restrict__ src,
                                                                        double *__restrict__ dst, LineMap map, int lg,
                                                                        int lp, const double2 *__restrict__ tw,
                                                                        const double2 *__restrict__ ww) {
@@ -563,12 +572,12 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_strided_wg(const doub
     const int rowStride = row_stride(n);
     const int npairs = 1 << lp;
     const int tid = threadIdx.x;
-    const i64 L0 = (i64)blockIdx.x << (lp + 1);
+    const i64 L0 = xcd_tile(blockIdx.x, gridDim.x) << (lp + 1);
     const int r = tid & (npairs - 1);
     const i64 L = L0 + 2 * r;
     const bool ok = L < map.nLines;
     const i64 lb = ok ? map.base(L) : 0;
-    const int kstep = DCT_WG_THREADS >> lp;
+    const int kstep = T >> lp;
     for (int k0 = tid >> lp; k0 < n; k0 += kstep * DCT_BATCH) {
         double2 gv[DCT_BATCH];
 #pragma unroll
@@ -583,8 +592,8 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_strided_wg(const doub
         }
     }
     __syncthreads();
-    if (MODE == 1) idct_combine_wg(lds, lp, lg, rowStride, tid, DCT_WG_THREADS, ww);
-    fft_rows_wg(lds, lp, lg, rowStride, tid, DCT_WG_THREADS, tw);
+    if (MODE == 1) idct_combine_wg(lds, lp, lg, rowStride, tid, T, ww);
+    fft_rows_wg(lds, lp, lg, rowStride, tid, T, tw);
     if (ok) {
         const double2 *rr = lds + r * rowStride;
         for (int k = tid >> lp; k < n; k += kstep) {
@@ -697,12 +706,32 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     if (dct_wg_enabled() && vec && mode != 2 && ((i64)n << lp) >= 2 * DCT_WG_THREADS) {
         static bool once_wg = false;
-        if (!once_wg) { allow_big_lds(k_dct_strided_wg<0>); allow_big_lds(k_dct_strided_wg<1>); once_wg = true; }
+        if (!once_wg) {
+            allow_big_lds(k_dct_strided_wg<0, 512>); allow_big_lds(k_dct_strided_wg<1, 512>);
+            allow_big_lds(k_dct_strided_wg<0, 1024>); allow_big_lds(k_dct_strided_wg<1, 1024>);
+            once_wg = true;
+        }
+        // long lines: one workgroup of 1024 threads with the whole LDS (twice the rows) keeps 16 waves per CU
+        // like two workgroups of 512 would, and widens the contiguous segment per line to 128 bytes
+        static const bool wide = !(getenv("DOTSOCP_DCT_WIDE") && atoi(getenv("DOTSOCP_DCT_WIDE")) == 0);
+        const size_t lds2 = lds * 2;
+        if (wide && lds2 <= DCT_LDS_MAX && lds2 > DCT_LDS_MAX / 2 && map.nLines >= ((i64)4 << lp)) {
+            const int lp2 = lp + 1;
+            const unsigned blocks2 = (unsigned)((map.nLines + ((i64)2 << lp2) - 1) / ((i64)2 << lp2));
+            if (mode == 0)
+                hipLaunchKernelGGL((k_dct_strided_wg<0, 1024>), dim3(blocks2), dim3(1024), lds2, st, src, dst, map, lg, lp2,
+                                   p->tw, p->ww);
+            else
+                hipLaunchKernelGGL((k_dct_strided_wg<1, 1024>), dim3(blocks2), dim3(1024), lds2, st, src, dst, map, lg, lp2,
+                                   p->tw, p->ww);
+            DS_HIP(hipGetLastError());
+            return 0;
+        }
         if (mode == 0)
-            hipLaunchKernelGGL((k_dct_strided_wg<0>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
+            hipLaunchKernelGGL((k_dct_strided_wg<0, 512>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
                                p->tw, p->ww);
         else
-            hipLaunchKernelGGL((k_dct_strided_wg<1>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
+            hipLaunchKernelGGL((k_dct_strided_wg<1, 512>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
                                p->tw, p->ww);
         DS_HIP(hipGetLastError());
         return 0;
