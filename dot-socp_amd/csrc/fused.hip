@@ -27,6 +27,8 @@
 #include "gather_tile.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace dotsocp {
 
 template <int MODE, int XB>
@@ -118,7 +120,8 @@ int fused_geometry(const Grid &g, FusedGeom &fg) {
     fg.nxblk = (g.nx + fg.XB - 1) / fg.XB;
     const i64 tiles = fg.nyblk * fg.nxblk;
     // enough workgroups to fill 256 CUs several times over; each extra chunk costs one recomputed cell
-    i64 chunks = (2048 + tiles - 1) / tiles;
+    static const i64 target = getenv("DOTSOCP_CONE_BLOCKS") ? atoll(getenv("DOTSOCP_CONE_BLOCKS")) : 2048;
+    i64 chunks = (target + tiles - 1) / tiles;
     if (chunks < 1) chunks = 1;
     i64 TC = (g.ncl + chunks - 1) / chunks;
     if (TC < 8) TC = 8;

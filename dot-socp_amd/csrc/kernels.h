@@ -99,6 +99,12 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *q2, const double *sx, const double *sy, const double *weight,
                        const double *tail_bx, const double *tail_by, double *q_out, double *alpha,
                        hipStream_t st);
+// q-step + alpha update (alpha_in -> alpha_out, distinct buffers) + rhs of the next iteration's phi-step
+int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                     const double *sx, const double *sy, const double *weight, const double *tail_bx,
+                     const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
+                     double *rhs, hipStream_t st);
+int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, double *rhs, hipStream_t st);
 // acc-ADMM flavour (solver_socp_accADMM.m:229-237): same q, alpha_out = (alpha_in + A phi) - w.*q
 int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, double *q_out,

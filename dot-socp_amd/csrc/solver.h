@@ -53,6 +53,7 @@ struct Slab {
     KktWork kw{};
     // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
     double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
+    double *alpha2 = nullptr;   // ping-pong partner of alpha (q-step that also forms the next rhs)
     FusedGeom fg{};
     // acc-ADMM loop (solver_acc.hip): x^+ of the iteration (q^+ lives in q_old, beta^+ in beta2) and the
     // Halpern anchors / previous extrapolation points
@@ -159,6 +160,8 @@ struct Solver {
     int exchange_u0_tail();
     int group_begin();
     int group_end();
+    bool qrhs = true;        // DOTSOCP_QRHS=0: separate q-step and rhs kernels
+    bool rhs_valid = false;  // w0 holds A'(w.*q - alpha) + c of the current iterate (left there by the q-step)
     bool u0_fresh = false;   // u0_prev holds w.*q0 - alpha0 of the CURRENT iterate of the left neighbour
     // every slab with a neighbour in direction `dir` (+1 right, -1 left) sends `count` doubles
     // from src(slab) to dst(neighbour)

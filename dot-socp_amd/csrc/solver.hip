@@ -36,7 +36,7 @@ void Solver::free_slabs() {
         dfree(s.a0_prev); dfree(s.a0w_prev); dfree(s.btail_bx); dfree(s.btail_by);
         dfree(s.send_plane); dfree(s.send_plane2); dfree(s.send_bx); dfree(s.send_by);
         dfree(s.kw.partials); dfree(s.kw.sums);
-        dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy);
+        dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy); dfree(s.alpha2);
         dfree(s.phi_p); dfree(s.alpha_p); dfree(s.z_p);
         dfree(s.phi_a); dfree(s.q_a); dfree(s.alpha_a); dfree(s.z_a); dfree(s.beta_a);
     }
@@ -114,6 +114,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     overlap = nslabs > 1;                         // pays when there is communication to hide
     if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
+    if (const char *e = getenv("DOTSOCP_QRHS")) qrhs = (atoi(e) != 0);
     DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
     DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
     py = dct_plan_create(ny);
@@ -168,6 +169,7 @@ int Solver::alloc_slabs(int first, int count) {
             DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
             DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, stream));
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, stream));
+            DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, stream));
         }
         s.kw.maxBlocks = kkt_partials_needed(g);
         DS_CHECK(dzalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT, stream));
@@ -513,6 +515,7 @@ int Solver::flush_beta() {
 
 int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
     u0_fresh = false;      // q0 / alpha0 change: the u0 tail held by the right neighbour is stale
+    rhs_valid = false;     // ... and so is the right-hand side the last q-step left in w0
     if (fused && begun) {
         // beta: applied by the next pass that reads it (one op can be pending at a time)
         DS_CHECK(flush_beta());
@@ -579,6 +582,7 @@ int Solver::begin(const dotsocp_opts *o) {
     deferred = false;
     z_valid = true;
     z_prev_ok = false;
+    rhs_valid = false;
     hist_kkt.clear(); hist_time.clear(); hist_iter.clear(); hist_gap.clear();
     for (int i = 0; i < PH_COUNT; ++i) { phase_ms[i] = 0; phase_launches[i] = 0; }
     begun = true;
@@ -630,7 +634,14 @@ int Solver::phase_phi() {
         prof_end(PH_COMM);
     }
     prof_begin(PH_RHS);
-    for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, stream));
+    if (!rhs_valid) {
+        for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, stream));
+    } else if (multi()) {
+        // the q-step left rhs in w0; its first layer still lacks the left neighbour's last cell
+        for (auto &s : slabs)
+            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, stream));
+    }
+    rhs_valid = false;
     prof_end(PH_RHS);
     prof_begin(PH_POISSON);
     DS_CHECK(poisson_all());
@@ -699,12 +710,20 @@ int Solver::phase_q() {
             DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
         } else {
             // q^{k+1} goes to the buffer that held q^{k-1}; q^k is kept for the deferred beta update
-            DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.q_old,
-                                        s.alpha, stream));
+            if (qrhs) {
+                // ... and the right-hand side of the next phi-step is formed in the same pass (alpha ping-pongs)
+                DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.c,
+                                          s.q_old, s.alpha, s.alpha2, s.w0, stream));
+                std::swap(s.alpha, s.alpha2);
+            } else {
+                DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by,
+                                            s.q_old, s.alpha, stream));
+            }
             std::swap(s.q, s.q_old);
         }
     }
     prof_end(PH_QSTEP);
+    rhs_valid = fused && qrhs;
     DS_CHECK(exchange_q_halo(true));
     return 0;
 }

@@ -32,6 +32,7 @@ int Solver::acc_alloc() {
             DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
             DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, stream));
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, stream));
+            DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, stream));
         }
         if (s.phi_p) continue;
         DS_CHECK(dzalloc(&s.phi_p, g.NphiAlloc, stream));

@@ -6,6 +6,8 @@
 #include "device_utils.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace dotsocp {
 
 static inline dim3 tile_grid(const Grid &g, i64 layers) {
@@ -260,6 +262,189 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *tail_by, double *q_out, double *alpha, hipStream_t st) {
     return weight ? launch_qstep_fused_t<true>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st)
                   : launch_qstep_fused_t<false>(g, c, fg, phi, q2, sx, sy, weight, tail_bx, tail_by, q_out, alpha, st);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// q-step + alpha update + the NEXT iteration's right-hand side in one pass (fused dataflow):
+//   q^{k+1}, alpha^{k+1} as in k_qstep_fused, then rhs = A'(w.*q^{k+1} - alpha^{k+1}) + c (solver_socp_inPALM.m:194
+//   of iteration k+1) while u = w.*q - alpha is still in registers: saves re-reading q and alpha (6 of the 8
+//   arrays k_rhs streams).  A workgroup owns a 64 (y) x 4 (x) tile of nodes and marches through a chunk of
+//   time layers; the thread of node (y, x, tl) owns the q0 entry of the cell that starts there and the bx /
+//   by edges that leave it.  u of the t-1 cell is carried in a register, u of the x-1 edge comes through LDS,
+//   u of the y-1 edge through a lane shuffle; on a tile / chunk boundary the neighbour's entry is recomputed
+//   (reads only -- alpha is ping-ponged, so no other workgroup's writes are observed).  The sum order is the
+//   one of rhs_value().  Time-slab mode: the term of the left neighbour's last cell is added by k_rhs_fixup
+//   after the u0 exchange.
+// ---------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__device__ __forceinline__ void q_value(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
+                                        const double *__restrict__ weight, const double *__restrict__ alpha_in,
+                                        double &qn, double &an, double &u) {
+    const double a = alpha_in[k];
+    if (WEIGHTED) {
+        const double w = weight[k];
+        const double di = 1.0 / (diag_c + w * w);
+        qn = (w * (tmp + a) + q2) * di;
+        const double r = tmp - w * qn;
+        an = a + c.tau * r;
+        u = w * qn - an;
+    } else {
+        qn = (tmp + a + q2) * dinv;
+        const double r = tmp - qn;
+        an = a + c.tau * r;
+        u = qn - an;
+    }
+}
+
+struct QRhsArgs {
+    const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
+    double *q_out, *alpha_out, *rhs;
+    i64 TC;
+};
+
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
+    __shared__ double xch[2][TILE_X][TILE_Y];
+    const int lane = threadIdx.x, xl = threadIdx.y;
+    const i64 y = (i64)blockIdx.x * TILE_Y + lane;
+    const i64 x = (i64)blockIdx.y * TILE_X + xl;
+    const bool inb = (y < g.ny) && (x < g.nx);
+    const i64 t0 = (i64)blockIdx.z * a.TC;
+    const i64 t1 = (t0 + a.TC < g.ntl) ? t0 + a.TC : g.ntl;
+    auto bx_q2 = [&](i64 yy, i64 xx, i64 tl, i64 e) {
+        double q2 = a.q2v[e];
+        if ((xx % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + a.sx[(tl * fg.nxblk + (xx / fg.XB + 1)) * g.ny + yy]);
+        if (tl == 0 && !g.first) q2 += a.tail_bx[yy + g.ny * xx];
+        return q2;
+    };
+    auto by_q2 = [&](i64 yy, i64 xx, i64 tl, i64 e) {
+        double q2 = a.q2v[e];
+        if ((yy & 63) == 63) q2 = c.sf * (q2 + a.sy[(tl * g.nx + xx) * fg.nyblk + (yy / 64 + 1)]);
+        if (tl == 0 && !g.first) q2 += a.tail_by[yy + (g.ny - 1) * xx];
+        return q2;
+    };
+    double u0prev = 0.0;
+    double p0 = 0.0;
+    if (inb) {
+        const i64 node0 = y + g.ny * (x + g.nx * t0);
+        p0 = a.phi[node0];
+        if (t0 > 0) {       // cell in front of the chunk (owned by the previous chunk): recompute, do not store
+            const i64 k = node0 - g.plane;
+            double tmp = (-c.at) * a.phi[k];
+            tmp += c.at * p0;
+            double qn, an;
+            q_value<WEIGHTED>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev);
+        }
+    }
+    int par = 0;
+    for (i64 tl = t0; tl < t1; ++tl) {
+        const i64 node = y + g.ny * (x + g.nx * tl);
+        const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
+        const double dc = tbnd ? c.c2 : c.c1;
+        const double di = tbnd ? c.dinv2 : c.dinv1;
+        double pT = 0.0, u0 = 0.0, ubx = 0.0, uby = 0.0;
+        if (inb) {
+            double qn, an;
+            if (tl < g.ncl) {
+                pT = a.phi[node + g.plane];
+                double tmp = (-c.at) * p0;
+                tmp += c.at * pT;
+                q_value<WEIGHTED>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
+                a.q_out[node] = qn;
+                a.alpha_out[node] = an;
+            }
+            if (x < g.nx - 1) {
+                const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+                double tmp = (-c.ax) * p0;
+                tmp += c.ax * a.phi[node + g.ny];
+                q_value<WEIGHTED>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx);
+                a.q_out[e] = qn;
+                a.alpha_out[e] = an;
+            }
+            if (y < g.ny - 1) {
+                const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+                double tmp = (-c.ay) * p0;
+                tmp += c.ay * a.phi[node + 1];
+                q_value<WEIGHTED>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby);
+                a.q_out[e] = qn;
+                a.alpha_out[e] = an;
+            }
+        }
+        xch[par][xl][lane] = ubx;
+        __syncthreads();
+        double uby_m = __shfl_up(uby, 1, 64);
+        if (inb) {
+            double ubx_m = 0.0;
+            if (x >= 1) {
+                if (xl > 0) {
+                    ubx_m = xch[par][xl - 1][lane];
+                } else {            // edge owned by the tile to the left
+                    const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * (x - 1);
+                    double tmp = (-c.ax) * a.phi[node - g.ny];
+                    tmp += c.ax * p0;
+                    double qn, an;
+                    q_value<WEIGHTED>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m);
+                }
+            }
+            if (y >= 1 && lane == 0) {      // edge owned by the tile below
+                const i64 e = g.offBy + g.byLayer * tl + (y - 1) + (g.ny - 1) * x;
+                double tmp = (-c.ay) * a.phi[node - 1];
+                tmp += c.ay * p0;
+                double qn, an;
+                q_value<WEIGHTED>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m);
+            }
+            double r = 0.0;
+            if (tl >= 1) r += c.at * u0prev;
+            if (tl < g.ncl) r += (-c.at) * u0;
+            if (x >= 1) r += c.ax * ubx_m;
+            if (x <= g.nx - 2) r += (-c.ax) * ubx;
+            if (y >= 1) r += c.ay * uby_m;
+            if (y <= g.ny - 2) r += (-c.ay) * uby;
+            a.rhs[node] = r + a.cvec[node];
+        }
+        u0prev = u0;
+        p0 = pT;
+        par ^= 1;
+    }
+}
+
+int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
+                     const double *sx, const double *sy, const double *weight, const double *tail_bx,
+                     const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
+                     double *rhs, hipStream_t st) {
+    QRhsArgs a{phi, q2, sx, sy, weight, tail_bx, tail_by, cvec, alpha_in, q_out, alpha_out, rhs, 0};
+    // short chunks of time layers (measured at 1024x1024x128: 3.45 ms with 8-layer chunks, 4.2 ms with one chunk per
+    // tile -- the march is latency-bound per workgroup); each extra chunk recomputes one cell
+    const i64 tiles = fg.nyblk * fg.nxblk;
+    static const i64 target = getenv("DOTSOCP_QRHS_BLOCKS") ? atoll(getenv("DOTSOCP_QRHS_BLOCKS")) : 32768;
+    i64 chunks = (target + tiles - 1) / tiles;
+    i64 TC = (g.ntl + chunks - 1) / chunks;
+    if (TC < 8) TC = 8;
+    if (TC > g.ntl) TC = g.ntl;
+    a.TC = TC;
+    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)((g.ntl + TC - 1) / TC));
+    dim3 blk(TILE_Y, TILE_X);
+    if (weight) hipLaunchKernelGGL(k_qstep_rhs<true>, grid, blk, 0, st, g, c, fg, a);
+    else hipLaunchKernelGGL(k_qstep_rhs<false>, grid, blk, 0, st, g, c, fg, a);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// time-slab mode: rhs(:, :, first layer) += (D/ht) * u0 of the left neighbour's last cell
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs_fixup(Grid g, double at, const double *__restrict__ u0_prev,
+                                                               double *__restrict__ rhs) {
+    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
+    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    if (y >= g.ny || x >= g.nx) return;
+    const i64 i = y + g.ny * x;
+    rhs[i] = rhs[i] + at * u0_prev[i];
+}
+
+int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, double *rhs, hipStream_t st) {
+    hipLaunchKernelGGL(k_rhs_fixup, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c.at, u0_prev, rhs);
+    DS_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
