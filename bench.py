@@ -135,7 +135,9 @@ def main():
         ny, nx, nt = 1024, 1024, 128
     if D.capi.lib().dotsocp_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libdotsocp has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a box with fewer GPUs than ranks (tests/test_gpu_multiprocess.py): ranks share devices
+    device = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     dist, rccl = None, None
     if world > 1:
         # one process per GPU: torch.distributed (RCCL) carries the rendezvous, the barriers and the
@@ -144,10 +146,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        # DOTSOCP_BENCH_BACKEND=gloo: rehearsal only (several ranks on one GPU, with DOTSOCP_RCCL_LIB pointing at
+        # the test stand-in); the driver's runs use RCCL for both communicators
+        backend = os.environ.get("DOTSOCP_BENCH_BACKEND", "nccl")
+        tdev = "cuda" if backend == "nccl" else "cpu"
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        uid = torch.zeros(128, dtype=torch.uint8, device=tdev)
         if rank == 0:
-            uid = torch.tensor(list(D.capi.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+            uid = torch.tensor(list(D.capi.rccl_unique_id()), dtype=torch.uint8, device=tdev)
         dist.broadcast(uid, 0)
         rccl = (bytes(uid.cpu().tolist()), rank, world)
         if args.workload != "dot2d":
@@ -163,7 +169,7 @@ def main():
         t0s, t1s = D.capi.slab_range(nt, world, rank)
         var, model = D.initialize_slab(rho0, rho1, nt, t0s, t1s)
         D.InitialScaling(var, model, True, None, dim=2)
-    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=local_rank, profiling=False, rccl=rccl,
+    ctx = D.InPALMContext(var, opts, model, weighted=weight is not None, device=device, profiling=False, rccl=rccl,
                           nslabs=args.nslabs, method=args.method)
 
     def fence():
@@ -183,7 +189,7 @@ def main():
     dt = time.perf_counter() - t0
     assert done == args.steps
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     hist, sigma = ctx.finish(download=False)

@@ -101,3 +101,38 @@ def test_one_process_per_slab_matches_single_process(world):
         # beta comes back multiplied by sigma (finish()), like the single-process run
         b = beta.reshape((NY, NX, ncl, 10), order="F")
         assert np.max(np.abs(b - beta1[:, :, t0:t0 + ncl])) <= 1e-9 * np.abs(beta1).max()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_under_torchrun_rehearsal(world):
+    """bench.py launched the way the driver launches it for N > 1 (python -m torch.distributed.run ...), with the
+    ranks sharing the one GPU of the test box: torch.distributed over gloo and the solver's communicator over
+    the shared-memory stand-in.  Checks the N > 1 code path of bench.py end to end: rendezvous, unique-id
+    broadcast, slab initialisation, timed region, max-over-ranks, ONE JSON line from rank 0 whose iterates agree
+    with the N = 1 run of the same grid (same KKT-check count, finite positive throughput)."""
+    import json
+    import socket
+    _build_fake()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DOTSOCP_RCCL_LIB=FAKE_SO, DOTSOCP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    grid = ["--grid", "64", "48", "16"]
+    common = ["--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + grid
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world)] + common
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == world and rec["steps"] == 12 and rec["scaling"] == "strong"
+    assert rec["metric"] == ref["metric"] and rec["config"]["grid"] == [64, 48, 16]
+    assert rec["config"]["kkt_checks_in_timed_region"] == ref["config"]["kkt_checks_in_timed_region"]
+    assert np.isfinite(rec["value"]) and rec["value"] > 0
+    assert rec["roofline"]["launches"] > 0 and rec["kernel_ms"]["comm"] > 0
