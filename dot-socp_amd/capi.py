@@ -75,6 +75,8 @@ SYMBOLS = {
     "dotsocp_begin": (ctypes.c_int, [vp, ctypes.POINTER(Opts)]),
     "dotsocp_begin_method": (ctypes.c_int, [vp, ctypes.POINTER(Opts), ctypes.c_int, ctypes.POINTER(AccOpts)]),
     "dotsocp_run": (ctypes.c_int, [vp, i64, ctypes.POINTER(i64)]),
+    "dotsocp_recover_outputs": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dotsocp_jump_next_level": (ctypes.c_int, [vp, vp]),
     "dotsocp_finish": (ctypes.c_int, [vp, ctypes.POINTER(Result)]),
     "dotsocp_get_history": (ctypes.c_int, [vp, vp, vp, vp, vp]),
     "dotsocp_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),

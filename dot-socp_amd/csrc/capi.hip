@@ -280,6 +280,19 @@ int dotsocp_begin_method(dotsocp_ctx *ctx, const dotsocp_opts *opts, int method,
     CTX_OR_FAIL();
     return ctx->s.begin_method(opts, method, acc);
 }
+int dotsocp_recover_outputs(dotsocp_ctx *ctx, const double *rho0, const double *rho1, double *rho, double *Ex,
+                            double *Ey, double *q0, double *bx, double *by) {
+    CTX_OR_FAIL();
+    if (ctx->s.prob.dim == 1)     // 1-D problems live in the y slot of the engine (ny = nx1d, nx = 1)
+        return ctx->s.recover_outputs(rho0, rho1, rho, nullptr, Ex, q0, nullptr, bx);
+    return ctx->s.recover_outputs(rho0, rho1, rho, Ex, Ey, q0, bx, by);
+}
+
+int dotsocp_jump_next_level(dotsocp_ctx *coarse, dotsocp_ctx *fine) {
+    if (!coarse || !fine) { set_error("context is NULL"); return DOTSOCP_EINVAL; }
+    return fine->s.jump_from(coarse->s);
+}
+
 int dotsocp_run(dotsocp_ctx *ctx, dotsocp_i64 n_iters, dotsocp_i64 *done) { CTX_OR_FAIL(); return ctx->s.run(n_iters, done); }
 int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res) { CTX_OR_FAIL(); return ctx->s.finish(res); }
 

@@ -92,6 +92,15 @@ int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom 
 int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
                       hipStream_t st);
 
+// ---------------- transfer.hip (driver steps on the device) ----------------
+int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, double *phif, double sc_in, double sc_out,
+                       hipStream_t st);
+int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, double *betaf, double *neg, double sc_in0,
+                        double sc_in1, double sc_out, hipStream_t st);
+int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t st);
+int launch_outputs(const Grid &g, const double *q, const double *alpha, const double *weight, const double *rho0,
+                   const double *rho1, double sig, double cD, double dD, int which, double *out, hipStream_t st);
+
 // ---------------- stencil.hip ----------------
 // q-step + alpha update reading the precomputed adjoint sums q2 (+ side buffers) of the fused kernel;
 // writes q^{k+1} into q_out (q^k stays intact for the deferred beta update).

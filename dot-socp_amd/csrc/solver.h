@@ -185,6 +185,10 @@ struct Solver {
     void acc_swap_state();
     int acc_on_sigma_factor(double factor);
     AccCoef acc_coef() const;
+    // driver steps on the device (solver_io.hip)
+    int recover_outputs(const double *rho0, const double *rho1, double *rho, double *Ex, double *Ey, double *q0,
+                        double *bx, double *by);
+    int jump_from(Solver &coarse);
     // PALM (solver_palm.hip)
     int palm_begin();
     int palm_step(bool *brk);

@@ -115,7 +115,7 @@ def initialize_slab(rho0, rho1, nt, t0, t1):
 def InitialScaling(var, model, scalingYes, lastLevelKKT=None, dim=2, weighted=False):
     """socp/dot2d/solver_dotsocp2d.m:304-365; 1-D: solver_dotsocp1d.m:263-300 (hMean = h^(1/2));
     weighted: solver_wdotsocp2d.m:297-343 (`adjust`, E2 safeguard 4)."""
-    h = 1.0 / getattr(model, "n_global", var.phi.size)
+    h = 1.0 / (model.n_global if hasattr(model, "n_global") else var.phi.size)
     hMean = h ** (1.0 / 3.0) if dim == 2 else h ** 0.5
     if lastLevelKKT is None or not hasattr(var, "E2"):
         Escale2 = np.sqrt(2.0)
@@ -143,7 +143,8 @@ def InitialScaling(var, model, scalingYes, lastLevelKKT=None, dim=2, weighted=Fa
         model.normc = norm_c / cScale
         model.normd = norm_d * E / dScale
         model.c = (1.0 / cScale) * model.c
-        var.phi = (1.0 / dScale) * var.phi
+        if var.phi is not None:                 # None: the state is produced on the device (multilevel warm start)
+            var.phi = (1.0 / dScale) * var.phi
         if var.q is not None:
             var.q = (D / dScale) * var.q
             var.z = (E / dScale) * var.z

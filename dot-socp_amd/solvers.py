@@ -46,10 +46,12 @@ class InPALMContext:
     """Stateful handle on one device-resident loop (create -> upload -> begin -> run* -> finish)."""
 
     def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False, rccl=None,
-                 method="inPALM"):
+                 method="inPALM", warm_from=None):
         """rccl = (unique_id_bytes, rank, world): one process per GPU, this process owns time slab
         `rank`; var / model then hold the LOCAL slab of every field (model.nt stays the global nt).
-        method: which loop file of the reference runs ("inPALM"/"ALG2" by opts.tau, "acc-ADMM")."""
+        method: which loop file of the reference runs ("inPALM"/"ALG2" by opts.tau, "PALM", "acc-ADMM").
+        warm_from: the finished context of the previous (coarser) multilevel level: phi, q, alpha, z, beta are
+        then produced on the device by jump_nextLevel.m's transfer instead of being uploaded from `var`."""
         L = capi.lib()
         self.method = method
         one_d = not hasattr(model, "ny")
@@ -70,12 +72,15 @@ class InPALMContext:
                 buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(uid))
                 capi.check(L.dotsocp_attach_rccl(self._ctx, buf, int(rk), int(wd)))
             # a field left as None keeps the device default (zeros), e.g. z, beta, q, alpha of a cold start
-            for f, a in ((capi.F_PHI, var.phi), (capi.F_Q, var.q), (capi.F_ALPHA, var.alpha),
-                         (capi.F_Z, var.z), (capi.F_BETA, var.beta), (capi.F_C, model.c)):
+            state = () if warm_from is not None else ((capi.F_PHI, var.phi), (capi.F_Q, var.q), (capi.F_ALPHA, var.alpha),
+                                                      (capi.F_Z, var.z), (capi.F_BETA, var.beta))
+            for f, a in state + ((capi.F_C, model.c),):
                 if a is not None:
                     self.upload(f, a)
             if weighted:
                 self.upload(capi.F_WEIGHT, model.weight)
+            if warm_from is not None:
+                capi.check(L.dotsocp_jump_next_level(warm_from._ctx, self._ctx))
             if profiling:
                 capi.check(L.dotsocp_set_profiling(self._ctx, 1))
             o = capi.Opts()
@@ -153,6 +158,22 @@ class InPALMContext:
         runHist = dict(kkt=kkt, time=tm, iter=itr, pdGap=gap, len=n)
         self.result = res
         return runHist, res.sigma
+
+    def outputs(self):
+        """solver_dotsocp2d.m:262-281 on the device (recoverOrgVar + recover_RhoE + recover_q): dict with rho, Ex,
+        [Ey,] q0, bx[, by]; call after finish()."""
+        m = self.model
+        one_d = not hasattr(m, "ny")
+        nt = int(m.nt)
+        shp = (int(m.nx),) if one_d else (int(m.ny), int(m.nx))
+        names = ("rho", "Ex", "q0", "bx") if one_d else ("rho", "Ex", "Ey", "q0", "bx", "by")
+        out = {k: np.empty(shp + ((nt - 1,) if k in ("q0", "bx", "by") else (nt,)), order="F") for k in names}
+        r0 = np.asfortranarray(m.rho0, dtype=np.float64)
+        r1 = np.asfortranarray(m.rho1, dtype=np.float64)
+        ptr = lambda k: capi.fptr(out[k]) if k in out else None      # noqa: E731
+        capi.check(capi.lib().dotsocp_recover_outputs(self._ctx, capi.fptr(r0), capi.fptr(r1), ptr("rho"), ptr("Ex"),
+                                                      ptr("Ey"), ptr("q0"), ptr("bx"), ptr("by")))
+        return out
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -235,13 +256,18 @@ def _driver_opts(opts, method, weighted, dim=2):
     return o
 
 
-def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, barrier=None):
+def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, barrier=None, transfer="device"):
     """The level loop of solver_dotsocp2d.m:154-250 (dot1d / wdot2d twins): restrict the data to
-    levelN grids, solve coarse to fine with warm starts; every solve runs on the device."""
+    levelN grids, solve coarse to fine with warm starts; every solve runs on the device.
+    transfer = "device": the state never leaves the GPU -- jump_nextLevel and the output recovery run there
+    (dotsocp_jump_next_level / dotsocp_recover_outputs); "host": download, numpy twins of jump_nextLevel.m /
+    recover_RhoE.m / recover_q.m, upload (the two agree to rounding, tests/test_multilevel.py)."""
     from . import multilevel as ML
     from .examples import ensure_barrier_validity
     if not (isinstance(levelN, (int, np.integer)) and levelN >= 1):
         raise ValueError("Invalid input at position 4 (Number of levels in multilevel strategy)")
+    if transfer not in ("device", "host"):
+        raise ValueError("transfer must be 'device' or 'host'")
     o = _driver_opts(opts, method, weighted, dim)
     t_all = time.perf_counter()
     tolFactor = -1.0 if o["tol"] > 0.99e-3 else -0.5                     # :124-128
@@ -268,69 +294,94 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
         N = rho0s[lv].size
         rho0s[lv] = rho0s[lv] / (rho0s[lv].sum() / N)
         rho1s[lv] = rho1s[lv] / (rho1s[lv].sum() / N)
-    var, model = initialize(rho0s[0], rho1s[0], nts[0])
+    on_device = transfer == "device"
+    var, model = initialize(rho0s[0], rho1s[0], nts[0], lazy_zeros=on_device)
     if weighted:
         model.weight = ws[0]
-    if method == "acc-ADMM":                                             # :224-225
-        solve = solver_wsocp_accADMM if weighted else solver_socp_accADMM
-    elif method == "PALM":                                               # :205-206
-        solve = solver_socp_PALM
-    else:
-        solve = solver_wsocp_inPALM if weighted else solver_socp_inPALM
     timeML, runHistML, runHist, last = [], None, None, None
-    for lv in range(L):
-        InitialScaling(var, model, o["scaling"], last, dim=dim, weighted=weighted)
-        runHist, sigma = solve(var, dict(o, tol=tols[lv]), model, device=device)
-        recoverOrgVar(var)
-        timeML.append(var.time)
-        if runHistML is None:                                            # catRunHist, :389-407
-            runHistML = {k: np.array(v, copy=True) if isinstance(v, np.ndarray) else v for k, v in runHist.items()}
-        else:
-            runHist["time"] = runHistML["time"][-1] + runHist["time"]
-            runHistML["kkt"] = np.concatenate([runHistML["kkt"], runHist["kkt"]], axis=0)
-            runHistML["pdGap"] = np.concatenate([runHistML["pdGap"], runHist["pdGap"]])
-            runHistML["time"] = np.concatenate([runHistML["time"], runHist["time"]])
-            runHistML["iter"] = np.concatenate([runHistML["iter"], runHistML["iter"][-1] + runHist["iter"]])
-            runHistML["len"] = runHistML["len"] + runHist["len"]
-        if lv < L - 1:
-            o["time_limit"] = o["time_limit"] - var.time["Total_Time"]   # :244
-            o["sigma"] = 10 ** (np.log10(o["sigma"] * sigma) / 2)         # :245
-            var, model = ML.jump_nextLevel(var, model, rho0s[lv + 1], rho1s[lv + 1], nts[lv + 1],
-                                           ws[lv + 1] if weighted else None)
-            last = runHist["kkt"][-1]
+    ctx = prev = None
+    try:
+        for lv in range(L):
+            InitialScaling(var, model, o["scaling"], last, dim=dim, weighted=weighted)
+            ctx = InPALMContext(var, dict(o, tol=tols[lv]), model, weighted=weighted, device=device, method=method,
+                                warm_from=prev)
+            if prev is not None:
+                prev.close()
+                prev = None
+            ctx.run(-1)
+            last_level = lv == L - 1
+            runHist, sigma = ctx.finish(download=not on_device)
+            timeML.append(var.time)
+            if runHistML is None:                                        # catRunHist, :389-407
+                runHistML = {k: np.array(v, copy=True) if isinstance(v, np.ndarray) else v for k, v in runHist.items()}
+            else:
+                runHist["time"] = runHistML["time"][-1] + runHist["time"]
+                runHistML["kkt"] = np.concatenate([runHistML["kkt"], runHist["kkt"]], axis=0)
+                runHistML["pdGap"] = np.concatenate([runHistML["pdGap"], runHist["pdGap"]])
+                runHistML["time"] = np.concatenate([runHistML["time"], runHist["time"]])
+                runHistML["iter"] = np.concatenate([runHistML["iter"], runHistML["iter"][-1] + runHist["iter"]])
+                runHistML["len"] = runHistML["len"] + runHist["len"]
+            if on_device and last_level:
+                output = ctx.outputs()
+            if not on_device:
+                ctx.close()
+                recoverOrgVar(var)
+            if not last_level:
+                o["time_limit"] = o["time_limit"] - var.time["Total_Time"]   # :244
+                o["sigma"] = 10 ** (np.log10(o["sigma"] * sigma) / 2)         # :245
+                last = runHist["kkt"][-1]
+                wf = ws[lv + 1] if weighted else None
+                if on_device:
+                    E2 = var.E2
+                    var, model = initialize(rho0s[lv + 1], rho1s[lv + 1], nts[lv + 1], lazy_zeros=True)
+                    var.phi, var.E2 = None, E2          # state comes from the coarse level on the device
+                    model.n_global = model.c.size
+                    if weighted:
+                        model.weight = wf
+                    prev = ctx
+                else:
+                    var, model = ML.jump_nextLevel(var, model, rho0s[lv + 1], rho1s[lv + 1], nts[lv + 1], wf)
+        if not on_device:
+            rho_E = recover_RhoE(var, model, weighted=weighted)
+            qs = recover_q(var, model)
+            if dim == 2:
+                output = dict(rho=rho_E[0], Ex=rho_E[1], Ey=rho_E[2], q0=qs[0], bx=qs[1], by=qs[2])
+            else:
+                output = dict(rho=rho_E[0], Ex=rho_E[1], q0=qs[0], bx=qs[1])
+    finally:
+        for c in (ctx, prev):
+            if c is not None:
+                c.close()
     timeML.append({"ML_Time": time.perf_counter() - t_all})
     name = ("Weighted-" if weighted else "") + "DOT-SOCP"
     mname = (f"{method} for {name}") if L == 1 else (f"Multilevel-{method} for {name}")
     runHist["method"] = runHistML["method"] = mname
-    return var, model, timeML, runHistML, runHist
+    return output, timeML, runHistML, runHist
 
 
-def solver_dotsocp2d(rho0, rho1, nt, levelN, opts, method="inPALM", device=0):
-    var, model, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 2, False, device)
-    rho, Ex, Ey = recover_RhoE(var, model)
-    q0, bx, by = recover_q(var, model)
-    output = dict(rho=rho, Ex=Ex, Ey=Ey, q0=q0, bx=bx, by=by)
-    if not check_massConservation(rho, 1e-2):
+def solver_dotsocp2d(rho0, rho1, nt, levelN, opts, method="inPALM", device=0, transfer="device"):
+    """[output, timeML, runHistML, runHist] = solver_dotsocp2d(rho0, rho1, nt, levelN, opts, method)
+    socp/dot2d/solver_dotsocp2d.m:1"""
+    output, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 2, False, device,
+                                                       transfer=transfer)
+    if not check_massConservation(output["rho"], 1e-2):
         print("Warning: The mass conservation constraint violation exceeds 0.01")
     return output, timeML, runHistML, runHist
 
 
-def solver_dotsocp1d(rho0, rho1, nt, levelN, opts, method="inPALM", device=0):
-    var, model, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 1, False, device)
-    rho, Ex = recover_RhoE(var, model)
-    q0, bx = recover_q(var, model)
-    output = dict(rho=rho, Ex=Ex, q0=q0, bx=bx)
-    if not check_massConservation(rho, 1e-2):
+def solver_dotsocp1d(rho0, rho1, nt, levelN, opts, method="inPALM", device=0, transfer="device"):
+    """socp/dot1d/solver_dotsocp1d.m:1"""
+    output, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 1, False, device,
+                                                       transfer=transfer)
+    if not check_massConservation(output["rho"], 1e-2):
         print("Warning: The mass conservation constraint violation exceeds 0.01")
     return output, timeML, runHistML, runHist
 
 
-def solver_wdotsocp2d(rho0, rho1, nt, levelN, opts, method="inPALM", barrier=None, device=0):
-    var, model, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 2, True, device,
-                                                          barrier=barrier)
-    rho, Ex, Ey = recover_RhoE(var, model, weighted=True)
-    q0, bx, by = recover_q(var, model)
-    output = dict(rho=rho, Ex=Ex, Ey=Ey, q0=q0, bx=bx, by=by)
-    if not check_massConservation(rho, 1e-2):
+def solver_wdotsocp2d(rho0, rho1, nt, levelN, opts, method="inPALM", barrier=None, device=0, transfer="device"):
+    """socp/wdot2d/solver_wdotsocp2d.m:1"""
+    output, timeML, runHistML, runHist = _solve_levels(rho0, rho1, nt, levelN, opts, method, 2, True, device,
+                                                       barrier=barrier, transfer=transfer)
+    if not check_massConservation(output["rho"], 1e-2):
         print("Warning: The tolerance of mass conservation constraint is under 0.01")
     return output, timeML, runHistML, runHist

@@ -202,6 +202,22 @@ int dotsocp_begin_method(dotsocp_ctx *ctx, const dotsocp_opts *opts, int method,
 int dotsocp_run(dotsocp_ctx *ctx, dotsocp_i64 n_iters, dotsocp_i64 *done);
 int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res);
 
+/* Driver outputs on the device: recoverOrgVar (socp/dot2d/solver_dotsocp2d.m:368-386) +
+ * recover_RhoE (utils/recover_RhoE.m:14-25; wdot2d: alpha = weight .* alpha, :11) + recover_q
+ * (utils/recover_q.m:12-22) from the device-resident alpha and q, so that only the outputs cross PCIe.  Call
+ * after finish().  rho0, rho1: model.rho0 / rho1 (ny x nx, host).  Outputs (host, column-major, any may be NULL):
+ * rho, Ex, Ey: ny x nx x nt;  q0, bx, by: ny x nx x (nt-1).  1-D problems: rho, Ex: nx x nt; q0, bx: nx x (nt-1);
+ * Ey, by ignored.  One-slab contexts only (DOTSOCP_EINVAL otherwise). */
+int dotsocp_recover_outputs(dotsocp_ctx *ctx, const double *rho0, const double *rho1, double *rho, double *Ex,
+                            double *Ey, double *q0, double *bx, double *by);
+
+/* Multilevel transfer on the device: socp/dot2d/utils/jump_nextLevel.m:5-16 with
+ * interpolate.m:20-84, between the finished context `coarse` and the context `fine` of the next level (created
+ * from the fine level's InitialScaling scalars, c and weight uploaded, begin() not yet called; grid
+ * 2 (n - 1) + 1 per dimension).  Fills phi, q, alpha, z, beta of `fine` exactly as recoverOrgVar ->
+ * jump_nextLevel -> InitialScaling -> upload would.  Same device, one-slab contexts. */
+int dotsocp_jump_next_level(dotsocp_ctx *coarse, dotsocp_ctx *fine);
+
 /* runHist.{kkt (len x 7, column-major), time, iter, pdGap} (:350-354); any pointer may be NULL */
 int dotsocp_get_history(dotsocp_ctx *ctx, double *kkt, double *time, double *iter, double *pdGap);
 

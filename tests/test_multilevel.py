@@ -65,11 +65,25 @@ def test_downsample_weights():
     np.testing.assert_allclose(OM.downSample_barrier(nt, nx, ny, w), PM.downSample_barrier(nt, nx, ny, w), rtol=1e-15)
 
 
+TRANSFERS = pytest.mark.parametrize("transfer", ["device", "host"])
+
+
 @pytest.mark.gpu
-def test_multilevel_dot2d_against_oracle():
+@TRANSFERS
+def test_multilevel_dot2d_against_oracle(transfer):
+    """transfer = "device": jump_nextLevel and the output recovery run on the GPU (dotsocp_jump_next_level,
+    dotsocp_recover_outputs); "host": numpy twins between device solves.  Both must reproduce the oracle's
+    per-level iteration counts and transport."""
     rho0, rho1 = get_example_2d("example1", 33, 33)
     ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, 17, 3, dict(tol=1e-4))
-    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 17, 3, dict(tol=1e-4), "inPALM")
+    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 17, 3, dict(tol=1e-4), "inPALM", transfer=transfer)
+    rq = D.recover_q(ovar, omodel)          # host twin of recover_q.m applied to the ORACLE's iterates
+    for k, ref in zip(("q0", "bx", "by"), rq):
+        assert out[k].shape == ref.shape
+        np.testing.assert_allclose(out[k], ref, atol=1e-6)
+    _, Ex_o, Ey_o = recover_RhoE(ovar, omodel)
+    np.testing.assert_allclose(out["Ex"], Ex_o, atol=1e-6)
+    np.testing.assert_allclose(out["Ey"], Ey_o, atol=1e-6)
     assert len(timeML) == 4
     assert [int(t["Iters"]) for t in timeML[:3]] == [int(h["iter"][-1]) for h in ohists]
     assert histML["len"] == sum(h["len"] for h in ohists)
@@ -80,17 +94,21 @@ def test_multilevel_dot2d_against_oracle():
 
 
 @pytest.mark.gpu
-def test_multilevel_dot1d_against_oracle():
+@TRANSFERS
+def test_multilevel_dot1d_against_oracle(transfer):
     rho0, rho1 = get_example_1d("gaussian", 129)
     ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, 33, 3, dict(tol=1e-4))
-    out, timeML, histML, hist = D.solver_dotsocp1d(rho0, rho1, 33, 3, dict(tol=1e-4), "inPALM")
+    out, timeML, histML, hist = D.solver_dotsocp1d(rho0, rho1, 33, 3, dict(tol=1e-4), "inPALM", transfer=transfer)
+    assert out["rho"].shape == (129, 33) and out["Ex"].shape == (129, 33)
+    assert out["q0"].shape == (129, 32) and out["bx"].shape == (129, 32)
     assert [int(t["Iters"]) for t in timeML[:3]] == [int(h["iter"][-1]) for h in ohists]
     rho_o, _ = recover_RhoE_1d(ovar, omodel)
     np.testing.assert_allclose(out["rho"], rho_o, atol=1e-6)
 
 
 @pytest.mark.gpu
-def test_multilevel_wdot2d_with_barrier_against_oracle():
+@TRANSFERS
+def test_multilevel_wdot2d_with_barrier_against_oracle(transfer):
     n, nt = 33, 17
     barrier = gene_barrier_of_circle_pillar()
     rho0, rho1 = get_example_2d("example1", n, n)
@@ -99,7 +117,45 @@ def test_multilevel_wdot2d_with_barrier_against_oracle():
     opts = dict(tol=1e-3, maxit=400)
     ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, nt, 2, opts, weight=weight, barrier=barrier,
                                                        ensure_barrier=ensure_barrier_validity)
-    out, timeML, histML, hist = D.solver_wdotsocp2d(rho0, rho1, nt, 2, dict(opts, weight=weight), "inPALM", barrier)
+    out, timeML, histML, hist = D.solver_wdotsocp2d(rho0, rho1, nt, 2, dict(opts, weight=weight), "inPALM", barrier,
+                                                    transfer=transfer)
     assert [int(t["Iters"]) for t in timeML[:2]] == [int(h["iter"][-1]) for h in ohists]
     rho_o, _, _ = recover_RhoE(ovar, omodel, weighted=True)
     np.testing.assert_allclose(out["rho"], rho_o, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["dot2d", "wdot2d", "dot1d"])
+def test_device_outputs_equal_host_recovery(case):
+    """dotsocp_recover_outputs against recoverOrgVar + recover_RhoE + recover_q on the downloaded iterates of the
+    same context: same arithmetic in the same order, so the results are identical."""
+    from oracle import driver as OD
+    weight = None
+    if case == "dot1d":
+        rho0, rho1 = get_example_1d("gaussian", 65)
+        nt, dim = 17, 1
+    else:
+        rho0, rho1 = get_example_2d("example1", 24, 40)
+        nt, dim = 12, 2
+        if case == "wdot2d":
+            barrier = gene_barrier_of_circle_pillar()
+            weight = get_weight_by_barrier(40, 24, nt, barrier)
+            rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    var, model = D.initialize(rho0, rho1, nt)
+    if weight is not None:
+        model.weight = weight
+    o = OD.default_opts(dict(tol=0.0, maxit=30), "inPALM", weight is not None)
+    D.InitialScaling(var, model, True, None, dim=dim, weighted=weight is not None)
+    ctx = D.InPALMContext(var, o, model, weighted=weight is not None)
+    ctx.run(-1)
+    ctx.finish(download=True)
+    dev = ctx.outputs()
+    ctx.close()
+    D.recoverOrgVar(var)
+    rE = D.recover_RhoE(var, model, weighted=weight is not None)
+    rq = D.recover_q(var, model)
+    names = ("rho", "Ex", "q0", "bx") if dim == 1 else ("rho", "Ex", "Ey", "q0", "bx", "by")
+    host = dict(zip(names, (rE + rq) if dim == 2 else (rE[0], rE[1], rq[0], rq[1])))
+    for k in names:
+        assert dev[k].shape == host[k].shape, k
+        np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
