@@ -10,9 +10,13 @@
 // LDS-staged tile (exact, O(n^2) per line; fallback path).
 #include "kernels.h"
 
+#include <dlfcn.h>
+#include <rocblas/rocblas.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace dotsocp {
@@ -660,6 +664,76 @@ __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, do
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense lengths through rocBLAS: for a non-power-of-two length (the 2^k+1 grids of the multilevel drivers)
+// the transform along an axis IS a plain matrix product with the n x n DCT matrix -- y: C X (one DGEMM),
+// x: X_t C' for every time layer (strided batch), t: X C' (one DGEMM) -- and a library DGEMM on the fp64
+// matrix cores is the right tool for it (1025 x 1025 x 129: 287 ms per Poisson solve with the LDS-tiled
+// kernel above, ~20 ms as DGEMMs).  librocblas is opened at run time, and only when such a length occurs;
+// without it (or with DOTSOCP_DENSE=kernel) k_dct_dense is used.
+// ---------------------------------------------------------------------------------------------
+struct RocBlas {
+    bool tried = false, ok = false;
+    rocblas_handle handle = nullptr;
+    decltype(&rocblas_create_handle) create = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocblas_set_atomics_mode) set_atomics = nullptr;
+    decltype(&rocblas_dgemm) dgemm = nullptr;
+    decltype(&rocblas_dgemm_strided_batched) dgemm_sb = nullptr;
+};
+
+static RocBlas &rocblas_api() {
+    static thread_local RocBlas api;     // one handle per host thread (contexts are single-threaded)
+    if (api.tried) return api;
+    api.tried = true;
+    if (const char *e = getenv("DOTSOCP_DENSE"))
+        if (strcmp(e, "kernel") == 0) return api;
+    void *h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return api;
+    api.create = (decltype(api.create))dlsym(h, "rocblas_create_handle");
+    api.set_stream = (decltype(api.set_stream))dlsym(h, "rocblas_set_stream");
+    api.set_atomics = (decltype(api.set_atomics))dlsym(h, "rocblas_set_atomics_mode");
+    api.dgemm = (decltype(api.dgemm))dlsym(h, "rocblas_dgemm");
+    api.dgemm_sb = (decltype(api.dgemm_sb))dlsym(h, "rocblas_dgemm_strided_batched");
+    if (!api.create || !api.set_stream || !api.dgemm || !api.dgemm_sb) return api;
+    if (api.create(&api.handle) != rocblas_status_success) return api;
+    if (api.set_atomics) (void)api.set_atomics(api.handle, rocblas_atomics_not_allowed);   // run-to-run identical sums
+    api.ok = true;
+    return api;
+}
+
+// out = DCT (inverse: DCT') along `axis` of the [n0][n1][n2] array as DGEMMs; false if rocBLAS is not usable
+static bool dense_axis_rocblas(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis,
+                               int inverse, hipStream_t st) {
+    RocBlas &rb = rocblas_api();
+    if (!rb.ok) return false;
+    const i64 n = p->n;
+    if (n0 * n1 > 0x7fffffff || n1 * n2 > 0x7fffffff || n2 > 0x7fffffff) return false;    // rocblas_int
+    if (rb.set_stream(rb.handle, st) != rocblas_status_success) return false;
+    const double one = 1.0, zero = 0.0;
+    const double *C = p->Cfwd;           // column-major n x n: C(k, j) = Cfwd[j * n + k]
+    rocblas_status rc;
+    if (axis == 0) {
+        // Out (n x L) = C X (forward) / C' X (inverse), L = n1 * n2
+        rc = rb.dgemm(rb.handle, inverse ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none,
+                      (rocblas_int)n, (rocblas_int)(n1 * n2), (rocblas_int)n, &one, C, (rocblas_int)n, src,
+                      (rocblas_int)n, &zero, dst, (rocblas_int)n);
+    } else if (axis == 1) {
+        // per layer t: Out_t (n0 x n) = X_t C' (forward) / X_t C (inverse)
+        rc = rb.dgemm_sb(rb.handle, rocblas_operation_none,
+                         inverse ? rocblas_operation_none : rocblas_operation_transpose, (rocblas_int)n0, (rocblas_int)n,
+                         (rocblas_int)n, &one, src, (rocblas_int)n0, n0 * n1, C, (rocblas_int)n, 0, &zero, dst,
+                         (rocblas_int)n0, n0 * n1, (rocblas_int)n2);
+    } else {
+        // Out (n0 n1 x n) = X C' (forward) / X C (inverse)
+        rc = rb.dgemm(rb.handle, rocblas_operation_none, inverse ? rocblas_operation_none : rocblas_operation_transpose,
+                      (rocblas_int)(n0 * n1), (rocblas_int)n, (rocblas_int)n, &one, src, (rocblas_int)(n0 * n1), C,
+                      (rocblas_int)n, &zero, dst, (rocblas_int)(n0 * n1));
+    }
+    return rc == rocblas_status_success;
+}
+
 #define DCT_LDS_BUDGET (72 * 1024)
 #define DCT_LDS_MAX (160 * 1024)
 
@@ -829,6 +903,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             set_error("dense DCT path needs distinct src/dst");
             return DOTSOCP_EINVAL;
         }
+        if (n >= 32 && total >= (i64)1 << 16 && dense_axis_rocblas(p, src, dst, n0, n1, n2, axis, inverse, st)) return 0;
         int TL = DENSE_TL;
         while (TL > 1 && (size_t)TL * n * sizeof(double) > 65536) TL >>= 1;
         while (TL > 1 && map.nLines < (i64)TL * 64) TL >>= 1;      // few lines: favour more workgroups

@@ -95,7 +95,8 @@ def test_bfd1d_and_conj1d(nt, nx):
 
 
 @pytest.mark.parametrize("shape", [(8, 4, 2), (64, 32, 16), (256, 8, 4), (16, 256, 8), (4, 16, 128), (1024, 2, 2),
-                                   (5, 6, 7), (33, 17, 9), (129, 3, 2), (16, 1, 8), (129, 1, 33)])
+                                   (5, 6, 7), (33, 17, 9), (129, 3, 2), (16, 1, 8), (129, 1, 33),
+                                   (129, 65, 33), (65, 129, 40), (257, 257, 5)])   # last three: DGEMM path (rocBLAS)
 def test_dctn_matches_scipy(shape):
     a = np.asfortranarray(rng.standard_normal(shape))
     tol = 2e-13 * np.sqrt(np.prod(shape))
@@ -112,7 +113,8 @@ def test_dctn_many_lines(shape):
     np.testing.assert_allclose(D.mirt_idctn(a), sfft.idctn(a, norm="ortho"), atol=2e-12)
 
 
-@pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32)])
+@pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32), (65, 65, 33),
+                                      (129, 64, 17)])
 def test_oper_poisson(ny, nx, nt):
     Dsc = 0.37
     rhs = np.asfortranarray(rng.standard_normal((ny, nx, nt)))
