@@ -8,6 +8,7 @@
 // lines are consecutive in y so that global accesses stay coalesced.
 // Other lengths (the 2^k+1 grids of the multilevel driver): dense DCT matrix applied from an
 // LDS-staged tile (exact, O(n^2) per line; fallback path).
+#include "device_utils.h"
 #include "kernels.h"
 
 #include <dlfcn.h>
@@ -108,15 +109,6 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 }
 
 __device__ __forceinline__ int bitrev(int k, int lg) { return (int)(__brev((unsigned)k) >> (32 - lg)); }
-
-// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  On the strided axes two
-// neighbouring tiles share every 128-byte line they touch (a tile row is 64 bytes wide for n = 1024), so the
-// tile index is permuted such that neighbouring tiles run on the SAME XCD back to back: the second one
-// hits in L2 instead of fetching the line from HBM a second time.  Bijection on [0, nb).
-__device__ __forceinline__ i64 xcd_tile(unsigned b, unsigned nb) {
-    const unsigned full = nb >> 3, rem = nb & 7u, r = b & 7u, q = b >> 3;
-    return (i64)r * full + (r < rem ? r : rem) + q;
-}
 
 #define DCT_THREADS 256
 #define DCT_WAVES 4

@@ -7,6 +7,32 @@ namespace dotsocp {
 #define TILE_Y 64
 #define TILE_X 4
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in the order of their linear index.
+// Where neighbouring tiles share cache lines -- the strided DCT axes (a tile row is 64 bytes wide for n = 1024)
+// and every tile kernel on grids whose row length is not a multiple of 16 doubles (the 2^k+1 grids) -- the tile
+// index is permuted such that neighbouring tiles run on the SAME XCD back to back: the second one hits in L2
+// instead of fetching the shared line from HBM again.  Bijection on [0, nb).
+__device__ __forceinline__ i64 xcd_tile(unsigned b, unsigned nb) {
+    const unsigned full = nb >> 3, rem = nb & 7u, r = b & 7u, q = b >> 3;
+    return (i64)r * full + (r < rem ? r : rem) + q;
+}
+
+// (x, y, z) block coordinates after that permutation of the linear block index (x fastest)
+struct BlockId {
+    unsigned x, y, z;
+};
+__device__ __forceinline__ BlockId block_id(bool remap) {
+    BlockId b{blockIdx.x, blockIdx.y, blockIdx.z};
+    if (remap) {
+        const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+        const i64 L = xcd_tile(b.x + gridDim.x * (b.y + gridDim.y * b.z), nb);
+        b.x = (unsigned)(L % gridDim.x);
+        b.y = (unsigned)((L / gridDim.x) % gridDim.y);
+        b.z = (unsigned)(L / ((i64)gridDim.x * gridDim.y));
+    }
+    return b;
+}
+
 // Row projection onto {x1 >= ||x_2..K||}; literal restatement of mexProjSoc's arithmetic
 // (SURVEY.md 8a a1): n = ||x_2..K||, c = clamp((x1/n + 1)/2, 0, 1) with NaN passing through,
 // x_j <- c x_j, x_1 <- (c >= 1) ? x_1 : c n.

@@ -35,11 +35,12 @@ template <int MODE, int XB>
 __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, FusedArgs a) {
     __shared__ double2 xch[2][XB][64];
     const int lane = threadIdx.x, xl = threadIdx.y;
-    const i64 y = (i64)blockIdx.x * 64 + lane;
-    const i64 x = (i64)blockIdx.y * XB + xl;
+    const BlockId blk = block_id(a.xcd != 0);
+    const i64 y = (i64)blk.x * 64 + lane;
+    const i64 x = (i64)blk.y * XB + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
     const i64 yc = inb ? y : 0, xc = inb ? x : 0;      // clamped coordinates keep out-of-tile lanes harmless
-    const i64 t0 = (i64)blockIdx.z * a.TC;
+    const i64 t0 = (i64)blk.z * a.TC;
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
     const bool lastChunk = (t1 == g.ncl);
     constexpr bool GATHER = (MODE < 2 || MODE == 4);
@@ -109,9 +110,15 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             for (int j = 0; j < 10; ++j) w[j] = 0.0;
         }
         if (GATHER)   // adjoint gather for edge layer tl (gather_tile.h)
-            gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blockIdx.y, blockIdx.x,
+            gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blk.y, blk.x,
                             a.q2, a.sx, a.sy);
     }
+}
+
+bool tile_xcd_remap(const Grid &g) {
+    static const int forced = getenv("DOTSOCP_XCD") ? atoi(getenv("DOTSOCP_XCD")) : -1;
+    if (forced >= 0) return forced != 0;
+    return (g.ny % 16) != 0;
 }
 
 int fused_geometry(const Grid &g, FusedGeom &fg) {
@@ -138,6 +145,7 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
                       hipStream_t st) {
     if (g.Nz <= 0) return 0;
     a.TC = fg.TC;
+    a.xcd = tile_xcd_remap(g) ? 1 : 0;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
     dim3 blk(64, 4);
     switch (mode) {

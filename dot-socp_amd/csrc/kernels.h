@@ -65,7 +65,10 @@ struct FusedArgs {
     // load exactly like k_scale would have: b = b * bmul / bdiv
     int bpend;
     double bmul, bdiv;
+    int xcd;                // permute the tile order so that y-neighbouring tiles share an XCD (device_utils.h)
 };
+// rows that are not a multiple of 16 doubles (128 bytes): neighbouring tiles share cache lines (2^k+1 grids)
+bool tile_xcd_remap(const Grid &g);
 int fused_geometry(const Grid &g, FusedGeom &fg);
 // mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z;
 // 3: z only, from (q_old, beta_in); 4: deferred beta update + gather of (z^k + beta^k) (PALM's first q-step)
