@@ -271,6 +271,7 @@ int dotsocp_attach_rccl(dotsocp_ctx *ctx, const unsigned char id[128], int rank,
 #define CTX_OR_FAIL()                                      \
     do {                                                   \
         if (!ctx) { set_error("ctx is NULL"); return DOTSOCP_EINVAL; } \
+        (void)hipGetLastError();   /* a stale error of an earlier, failed call must not be blamed on this one */ \
     } while (0)
 
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host) { CTX_OR_FAIL(); return ctx->s.upload(field, host); }

@@ -44,8 +44,10 @@ void Solver::free_slabs() {
 }
 
 Solver::~Solver() {
-    (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize(stream);
+    if (stream) {                 // init() got as far as the device: release what lives there
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+    }
     if (nccl) (void)rccl_api().CommDestroy((ncclComm_t)nccl);
     free_slabs();
     dct_plan_destroy(py); dct_plan_destroy(px); dct_plan_destroy(pt);

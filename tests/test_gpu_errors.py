@@ -1,0 +1,122 @@
+"""Error behaviour of the C ABI on a GPU box (include/dotsocp.h: status codes + dotsocp_last_error, no exceptions
+across the boundary) and the 1-D MEX operators' argument checks (mexBFd1d.mexa64 raises mexBFd:invalidNumInputs /
+invalidInput; the 2-D binaries validate nothing -- SURVEY.md 8b)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from dotsocp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(ny=16, nx=16, nt=8, dim=2, weighted=0):
+    p = capi.Problem()
+    p.dim, p.weighted, p.ny, p.nx, p.nt = dim, weighted, ny, nx, nt
+    p.D = p.E = p.cScale = p.dScale = 1.0
+    p.normc, p.normd = 1.0, 1.0
+    return p
+
+
+def _opts(maxit=3):
+    o = capi.Opts()
+    o.tau, o.sigma, o.tol, o.maxit = 1.9, 1.0, 0.0, maxit
+    o.ifCheckStepByStep, o.checkPrimDualFeas, o.scaling, o.time_limit = 0, -1, 1, 0.0
+    return o
+
+
+def _code(rc):
+    with pytest.raises(capi.DotsocpError) as e:
+        capi.check(rc)
+    return e.value.code
+
+
+def test_create_rejects_bad_problems():
+    L = capi.lib()
+    for bad in (_problem(dim=3), _problem(nt=1), _problem(nx=0)):
+        assert not L.dotsocp_create(ctypes.byref(bad), 0, 1)
+        assert L.dotsocp_last_error()
+    assert not L.dotsocp_create(ctypes.byref(_problem()), 99, 1)          # device ordinal
+    assert not L.dotsocp_create(ctypes.byref(_problem(nt=8)), 0, 5)        # more slabs than nt / 2
+
+
+def test_call_sequence_is_enforced():
+    L = capi.lib()
+    p = _problem()
+    ctx = L.dotsocp_create(ctypes.byref(p), 0, 1)
+    assert ctx
+    try:
+        done = capi.i64()
+        assert _code(L.dotsocp_run(ctx, 1, ctypes.byref(done))) == -4                 # run before begin
+        res = capi.Result()
+        assert _code(L.dotsocp_finish(ctx, ctypes.byref(res))) == -4                  # finish before begin
+        assert _code(L.dotsocp_upload(ctx, 17, None)) == -1                           # unknown field / NULL
+        assert _code(L.dotsocp_begin(ctx, None)) == -1
+        o = _opts()
+        o.sigma = 0.0
+        assert _code(L.dotsocp_begin(ctx, ctypes.byref(o))) == -1                     # sigma must be positive
+        o = _opts()
+        assert _code(L.dotsocp_begin_method(ctx, ctypes.byref(o), 7, None)) == -1     # unknown method
+        capi.check(L.dotsocp_begin(ctx, ctypes.byref(o)))
+        assert _code(L.dotsocp_begin(ctx, ctypes.byref(o))) == -4                     # begin twice
+        out = np.empty(8)
+        assert _code(L.dotsocp_recover_outputs(ctx, None, None, None, None, None, capi.fptr(out), None, None)) == -4
+        capi.check(L.dotsocp_run(ctx, -1, ctypes.byref(done)))
+        assert done.value == 3
+        capi.check(L.dotsocp_finish(ctx, ctypes.byref(res)))
+        assert res.iters == 3 and res.hist_len >= 1
+        assert _code(L.dotsocp_run(ctx, 1, ctypes.byref(done))) == -4                 # run after finish
+        ms, n = capi.dbl(), capi.i64()
+        assert _code(L.dotsocp_kernel_time(ctx, b"no_such_kernel", ctypes.byref(ms), ctypes.byref(n))) == -1
+    finally:
+        L.dotsocp_destroy(ctx)
+    assert _code(L.dotsocp_run(None, 1, None)) == -1                                  # NULL context
+
+
+def test_variant_restrictions():
+    L = capi.lib()
+    o = _opts()
+    for prob, method in ((_problem(ny=1, nx=32, dim=1), capi.METHOD_ACCADMM), (_problem(ny=1, nx=32, dim=1), capi.METHOD_PALM),
+                         (_problem(weighted=1), capi.METHOD_PALM)):
+        ctx = L.dotsocp_create(ctypes.byref(prob), 0, 1)
+        assert ctx
+        try:
+            assert _code(L.dotsocp_begin_method(ctx, ctypes.byref(o), method, None)) == -1
+        finally:
+            L.dotsocp_destroy(ctx)
+
+
+def test_jump_next_level_checks_the_grids():
+    L = capi.lib()
+    coarse = L.dotsocp_create(ctypes.byref(_problem(9, 9, 5)), 0, 1)
+    fine_ok = L.dotsocp_create(ctypes.byref(_problem(17, 17, 9)), 0, 1)
+    fine_bad = L.dotsocp_create(ctypes.byref(_problem(16, 17, 9)), 0, 1)
+    try:
+        assert _code(L.dotsocp_jump_next_level(coarse, fine_ok)) == -4                # coarse not finished
+        done, res = capi.i64(), capi.Result()
+        capi.check(L.dotsocp_begin(coarse, ctypes.byref(_opts())))
+        capi.check(L.dotsocp_run(coarse, -1, ctypes.byref(done)))
+        capi.check(L.dotsocp_finish(coarse, ctypes.byref(res)))
+        assert _code(L.dotsocp_jump_next_level(coarse, fine_bad)) == -1               # not 2 (n - 1) + 1
+        capi.check(L.dotsocp_jump_next_level(coarse, fine_ok))
+        assert _code(L.dotsocp_jump_next_level(None, fine_ok)) == -1
+    finally:
+        for c in (coarse, fine_ok, fine_bad):
+            L.dotsocp_destroy(c)
+
+
+def test_mex_1d_argument_errors():
+    """mexBFd1d / mexBFdConj1d: too few inputs and a non-scalar scale are errors (mexBFd:invalidNumInputs /
+    mexBFd:invalidInput in the reference binaries; a missing positional argument is a TypeError in Python)."""
+    z = np.zeros((4 * 3, 6), order="F")
+    q = np.zeros(4 * 3 + 3 * 4)
+    with pytest.raises(TypeError):
+        D.mexBFd1d(z, q, 4)
+    with pytest.raises(ValueError, match="invalidInput"):
+        D.mexBFd1d(z, q, 4, 4, np.ones(2))
+    with pytest.raises(TypeError):
+        D.mexBFdConj1d(q, z, 4)
+    with pytest.raises(ValueError, match="invalidInput"):
+        D.mexBFd1d(np.zeros((5, 6), order="F"), q, 4, 4)
