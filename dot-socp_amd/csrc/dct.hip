@@ -895,7 +895,11 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             set_error("dense DCT path needs distinct src/dst");
             return DOTSOCP_EINVAL;
         }
-        if (n >= 32 && total >= (i64)1 << 16 && dense_axis_rocblas(p, src, dst, n0, n1, n2, axis, inverse, st)) return 0;
+        // the library pays from ~20 GFLOP per pass on (513^2 x 129 and up); below that k_dct_dense needs a few ms at
+        // most and the one-time cost of loading rocBLAS (seconds: it pages in its kernel library) is not worth it
+        static const double min_flop = getenv("DOTSOCP_DENSE_MIN_GFLOP") ? 1e9 * atof(getenv("DOTSOCP_DENSE_MIN_GFLOP")) : 2e10;
+        if (2.0 * (double)n * (double)total >= min_flop && dense_axis_rocblas(p, src, dst, n0, n1, n2, axis, inverse, st))
+            return 0;
         int TL = DENSE_TL;
         while (TL > 1 && (size_t)TL * n * sizeof(double) > 65536) TL >>= 1;
         while (TL > 1 && map.nLines < (i64)TL * 64) TL >>= 1;      // few lines: favour more workgroups

@@ -96,13 +96,34 @@ def test_bfd1d_and_conj1d(nt, nx):
 
 @pytest.mark.parametrize("shape", [(8, 4, 2), (64, 32, 16), (256, 8, 4), (16, 256, 8), (4, 16, 128), (1024, 2, 2),
                                    (5, 6, 7), (33, 17, 9), (129, 3, 2), (16, 1, 8), (129, 1, 33),
-                                   (129, 65, 33), (65, 129, 40), (257, 257, 5)])   # last three: DGEMM path (rocBLAS)
+                                   (129, 65, 33), (65, 129, 40), (257, 257, 5)])
 def test_dctn_matches_scipy(shape):
     a = np.asfortranarray(rng.standard_normal(shape))
     tol = 2e-13 * np.sqrt(np.prod(shape))
     np.testing.assert_allclose(D.mirt_dctn(a), sfft.dctn(a, norm="ortho"), atol=tol)
     np.testing.assert_allclose(D.mirt_idctn(a), sfft.idctn(a, norm="ortho"), atol=tol)
     np.testing.assert_allclose(D.mirt_idctn(D.mirt_dctn(a)), a, atol=tol)
+
+
+def test_dctn_dense_lengths_through_dgemm():
+    """Non-power-of-two lengths above a work threshold go to rocBLAS DGEMM (y: C X, x: strided batch X_t C',
+    t: X C').  The threshold is lowered here so that small arrays take that path; it is read once per process,
+    hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, scipy.fft as sf, dotsocp_amd as D\n"
+        "rng = np.random.default_rng(7)\n"
+        "for shape in [(129, 65, 33), (65, 129, 40), (257, 130, 9)]:\n"
+        "    a = np.asfortranarray(rng.standard_normal(shape))\n"
+        "    np.testing.assert_allclose(D.mirt_dctn(a), sf.dctn(a, norm='ortho'), atol=2e-12)\n"
+        "    np.testing.assert_allclose(D.mirt_idctn(a), sf.idctn(a, norm='ortho'), atol=2e-12)\n"
+        "print('ok')\n")
+    env = dict(os.environ, DOTSOCP_DENSE_MIN_GFLOP="0.001")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("shape", [(1024, 1024, 16), (512, 2048, 8), (256, 4096, 8), (128, 8192, 8), (1024, 1023, 9)])
