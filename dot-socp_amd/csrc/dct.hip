@@ -652,6 +652,130 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_dense(const double *__restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Dense lengths on the fp64 matrix cores.  Along a non-power-of-two axis the transform is the product of the
+// n x n DCT matrix with the lines, out_l[k] = sum_j M[k][j] in_l[j]: v_mfma_f64_16x16x4_f64 tiles, a workgroup
+// computes 64 outputs k of 128 lines, its four waves 64 k x 32 lines each (4 x 2 accumulator tiles), the j
+// range streamed through LDS in double-buffered chunks of 16 (next chunk's global loads in flight in registers
+// during the MFMAs, one barrier per chunk).  M is staged as [j][k] (k contiguous, as stored); the lines as
+// [j][line] on the strided axes (lines consecutive in memory) and as [line][j] on axis 0 (j contiguous in memory),
+// so that global loads, LDS fragment reads (row strides 16 mod 32 doubles / 18 doubles: conflict-free) and the
+// stores of the 16 x 16 result tiles (16 consecutive addresses per row) are all coalesced.
+//   strided axes: D[k][line] = M . X      a = M fragment, b = line fragment
+//   axis 0      : D[line][k] = X' . M'    a = line fragment, b = M fragment
+// Operand / result lane maps of the f64 MFMA: a: A[lane & 15][lane >> 4], b: B[lane >> 4][lane & 15],
+// d[r]: D[(lane >> 4) + 4 r][lane & 15]   (cdna_hip_programming.md, fragment layout).
+// ---------------------------------------------------------------------------------------------
+typedef double mf_double4 __attribute__((ext_vector_type(4)));
+#define MF_KT 64
+#define MF_LT 128
+#define MF_KC 16
+#define MF_MS (MF_KT + 16)
+#define MF_XS (MF_LT + 16)      // strided axes: [j][line]
+#define MF_XZ (MF_KC + 2)       // axis 0: [line][j]
+
+template <bool AXIS0>
+__global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src, double *__restrict__ dst, LineMap map,
+                                                   int n, const double *__restrict__ M) {
+    __shared__ double Ms[2][MF_KC * MF_MS];
+    __shared__ double Xs[2][MF_KC * MF_XS];          // == MF_LT * MF_XZ doubles
+    static_assert(MF_KC * MF_XS == MF_LT * MF_XZ, "both stagings of the line tile have the same size");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int k0 = blockIdx.x * MF_KT;
+    const i64 L0 = (i64)blockIdx.y * MF_LT;
+    const int li = lane & 15, lh = lane >> 4;
+    mf_double4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (mf_double4){0.0, 0.0, 0.0, 0.0};
+    // ---- global -> register staging of one chunk ----
+    double mreg[4], xreg[8];
+    const int m_kk = tid & 63, m_jj = tid >> 6;                  // matrix: element (jj + 4 u, kk)
+    const bool m_ok = (k0 + m_kk) < n;
+    // lines: strided axes -> thread owns line ll = tid & 127, rows jj = (tid >> 7) + 2 u
+    //        axis 0       -> thread owns jj = tid & 15, lines ll = (tid >> 4) + 16 u
+    const int x_ll = AXIS0 ? (tid >> 4) : (tid & 127);
+    const int x_jj = AXIS0 ? (tid & 15) : (tid >> 7);
+    i64 xbase = 0;
+    bool x_ok = false;
+    if (!AXIS0) {
+        x_ok = (L0 + x_ll) < map.nLines;
+        xbase = x_ok ? map.base(L0 + x_ll) : 0;
+    }
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + m_jj + 4 * u;
+            mreg[u] = (m_ok && j < n) ? M[(i64)j * n + k0 + m_kk] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (AXIS0) {
+                const i64 L = L0 + x_ll + 16 * u;
+                const int j = j0 + x_jj;
+                xreg[u] = (L < map.nLines && j < n) ? src[L * n + j] : 0.0;
+            } else {
+                const int j = j0 + x_jj + 2 * u;
+                xreg[u] = (x_ok && j < n) ? src[xbase + (i64)j * map.nin] : 0.0;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ms[buf][(m_jj + 4 * u) * MF_MS + m_kk] = mreg[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (AXIS0) Xs[buf][(x_ll + 16 * u) * MF_XZ + x_jj] = xreg[u];
+            else Xs[buf][(x_jj + 2 * u) * MF_XS + x_ll] = xreg[u];
+        }
+    };
+    const int nch = (n + MF_KC - 1) / MF_KC;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nch) fetch((c + 1) * MF_KC);                  // in flight during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < MF_KC; kk += 4) {
+            double mf[4], xf[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) mf[a] = Ms[buf][(kk + lh) * MF_MS + a * 16 + li];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                xf[b] = AXIS0 ? Xs[buf][(wave * 32 + b * 16 + li) * MF_XZ + kk + lh]
+                              : Xs[buf][(kk + lh) * MF_XS + wave * 32 + b * 16 + li];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = AXIS0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(xf[b], mf[a], acc[a][b], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f64_16x16x4f64(mf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        if (c + 1 < nch) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- store the 4 x 2 result tiles ----
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (AXIS0) {
+                    const int k = k0 + a * 16 + li;
+                    const i64 L = L0 + wave * 32 + b * 16 + lh + 4 * r;
+                    if (k < n && L < map.nLines) dst[L * n + k] = acc[a][b][r];
+                } else {
+                    const int k = k0 + a * 16 + lh + 4 * r;
+                    const i64 L = L0 + wave * 32 + b * 16 + li;
+                    if (k < n && L < map.nLines) dst[map.base(L) + (i64)k * map.nin] = acc[a][b][r];
+                }
+            }
+}
+
 __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, double *__restrict__ dst, i64 n) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -895,10 +1019,23 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             set_error("dense DCT path needs distinct src/dst");
             return DOTSOCP_EINVAL;
         }
+        static const int dense_mode = [] {      // DOTSOCP_DENSE = mfma (default) | rocblas | kernel
+            const char *e = getenv("DOTSOCP_DENSE");
+            return (e && strcmp(e, "rocblas") == 0) ? 1 : ((e && strcmp(e, "kernel") == 0) ? 2 : 0);
+        }();
+        if (dense_mode == 0 && n >= 48 && map.nLines >= 64) {
+            const double *Mm = inverse ? p->Cinv : p->Cfwd;
+            dim3 grid((unsigned)((n + MF_KT - 1) / MF_KT), (unsigned)((map.nLines + MF_LT - 1) / MF_LT));
+            if (axis == 0) hipLaunchKernelGGL(k_dct_mfma<true>, grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+            else hipLaunchKernelGGL(k_dct_mfma<false>, grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+            DS_HIP(hipGetLastError());
+            return 0;
+        }
         // the library pays from ~20 GFLOP per pass on (513^2 x 129 and up); below that k_dct_dense needs a few ms at
         // most and the one-time cost of loading rocBLAS (seconds: it pages in its kernel library) is not worth it
         static const double min_flop = getenv("DOTSOCP_DENSE_MIN_GFLOP") ? 1e9 * atof(getenv("DOTSOCP_DENSE_MIN_GFLOP")) : 2e10;
-        if (2.0 * (double)n * (double)total >= min_flop && dense_axis_rocblas(p, src, dst, n0, n1, n2, axis, inverse, st))
+        if (dense_mode == 1 && 2.0 * (double)n * (double)total >= min_flop &&
+            dense_axis_rocblas(p, src, dst, n0, n1, n2, axis, inverse, st))
             return 0;
         int TL = DENSE_TL;
         while (TL > 1 && (size_t)TL * n * sizeof(double) > 65536) TL >>= 1;

@@ -106,8 +106,9 @@ def test_dctn_matches_scipy(shape):
 
 
 def test_dctn_dense_lengths_through_dgemm():
-    """Non-power-of-two lengths above a work threshold go to rocBLAS DGEMM (y: C X, x: strided batch X_t C',
-    t: X C').  The threshold is lowered here so that small arrays take that path; it is read once per process,
+    """DOTSOCP_DENSE=rocblas: non-power-of-two lengths above a work threshold as library DGEMMs (y: C X, x: strided
+    batch X_t C', t: X C') instead of the hand-written fp64-MFMA kernel that is the default (k_dct_mfma, exercised
+    by the non-power-of-two shapes of the tests around this one).  Mode and threshold are read once per process,
     hence the subprocess."""
     import os
     import subprocess
@@ -120,7 +121,7 @@ def test_dctn_dense_lengths_through_dgemm():
         "    np.testing.assert_allclose(D.mirt_dctn(a), sf.dctn(a, norm='ortho'), atol=2e-12)\n"
         "    np.testing.assert_allclose(D.mirt_idctn(a), sf.idctn(a, norm='ortho'), atol=2e-12)\n"
         "print('ok')\n")
-    env = dict(os.environ, DOTSOCP_DENSE_MIN_GFLOP="0.001")
+    env = dict(os.environ, DOTSOCP_DENSE="rocblas", DOTSOCP_DENSE_MIN_GFLOP="0.001")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
