@@ -657,7 +657,8 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_dense(const double *__restr
 // Dense lengths on the fp64 matrix cores.  Along a non-power-of-two axis the transform is the product of the
 // n x n DCT matrix with the lines, out_l[k] = sum_j M[k][j] in_l[j]: v_mfma_f64_16x16x4_f64 tiles, a workgroup
 // computes 64 outputs k of 128 lines, its four waves 64 k x 32 lines each (4 x 2 accumulator tiles), the j
-// range streamed through LDS in double-buffered chunks of 16 (next chunk's global loads in flight in registers
+// range streamed through LDS in double-buffered chunks of 8 (16: fewer barriers but half the resident workgroups,
+// 27.0 vs 24.3 ms per 1025^2 x 129 Poisson solve) (next chunk's global loads in flight in registers
 // during the MFMAs, one barrier per chunk).  M is staged as [j][k] (k contiguous, as stored); the lines as
 // [j][line] on the strided axes (lines consecutive in memory) and as [line][j] on axis 0 (j contiguous in memory),
 // so that global loads, LDS fragment reads (row strides 16 mod 32 doubles / 18 doubles: conflict-free) and the
@@ -670,17 +671,16 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_dense(const double *__restr
 typedef double mf_double4 __attribute__((ext_vector_type(4)));
 #define MF_KT 64
 #define MF_LT 128
-#define MF_KC 16
 #define MF_MS (MF_KT + 16)
 #define MF_XS (MF_LT + 16)      // strided axes: [j][line]
-#define MF_XZ (MF_KC + 2)       // axis 0: [line][j]
 
-template <bool AXIS0>
+template <bool AXIS0, int MF_KC>
 __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src, double *__restrict__ dst, LineMap map,
                                                    int n, const double *__restrict__ M) {
+    constexpr int MF_XZ = MF_KC + 2;                  // axis 0: [line][j]
+    constexpr int XSZ = (MF_KC * MF_XS > MF_LT * MF_XZ) ? MF_KC * MF_XS : MF_LT * MF_XZ;
     __shared__ double Ms[2][MF_KC * MF_MS];
-    __shared__ double Xs[2][MF_KC * MF_XS];          // == MF_LT * MF_XZ doubles
-    static_assert(MF_KC * MF_XS == MF_LT * MF_XZ, "both stagings of the line tile have the same size");
+    __shared__ double Xs[2][XSZ];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int k0 = blockIdx.x * MF_KT;
     const i64 L0 = (i64)blockIdx.y * MF_LT;
@@ -691,13 +691,14 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (mf_double4){0.0, 0.0, 0.0, 0.0};
     // ---- global -> register staging of one chunk ----
-    double mreg[4], xreg[8];
+    constexpr int MU = MF_KC / 4, XU = MF_KC / 2, ZSTEP = 256 / MF_KC;
+    double mreg[MU], xreg[XU];
     const int m_kk = tid & 63, m_jj = tid >> 6;                  // matrix: element (jj + 4 u, kk)
     const bool m_ok = (k0 + m_kk) < n;
     // lines: strided axes -> thread owns line ll = tid & 127, rows jj = (tid >> 7) + 2 u
-    //        axis 0       -> thread owns jj = tid & 15, lines ll = (tid >> 4) + 16 u
-    const int x_ll = AXIS0 ? (tid >> 4) : (tid & 127);
-    const int x_jj = AXIS0 ? (tid & 15) : (tid >> 7);
+    //        axis 0       -> thread owns jj = tid % KC, lines ll = tid / KC + (256 / KC) u
+    const int x_ll = AXIS0 ? (tid / MF_KC) : (tid & 127);
+    const int x_jj = AXIS0 ? (tid % MF_KC) : (tid >> 7);
     i64 xbase = 0;
     bool x_ok = false;
     if (!AXIS0) {
@@ -706,14 +707,14 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
     }
     auto fetch = [&](int j0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
             const int j = j0 + m_jj + 4 * u;
             mreg[u] = (m_ok && j < n) ? M[(i64)j * n + k0 + m_kk] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < XU; ++u) {
             if (AXIS0) {
-                const i64 L = L0 + x_ll + 16 * u;
+                const i64 L = L0 + x_ll + ZSTEP * u;
                 const int j = j0 + x_jj;
                 xreg[u] = (L < map.nLines && j < n) ? src[L * n + j] : 0.0;
             } else {
@@ -724,10 +725,10 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Ms[buf][(m_jj + 4 * u) * MF_MS + m_kk] = mreg[u];
+        for (int u = 0; u < MU; ++u) Ms[buf][(m_jj + 4 * u) * MF_MS + m_kk] = mreg[u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (AXIS0) Xs[buf][(x_ll + 16 * u) * MF_XZ + x_jj] = xreg[u];
+        for (int u = 0; u < XU; ++u) {
+            if (AXIS0) Xs[buf][(x_ll + ZSTEP * u) * MF_XZ + x_jj] = xreg[u];
             else Xs[buf][(x_jj + 2 * u) * MF_XS + x_ll] = xreg[u];
         }
     };
@@ -1026,8 +1027,14 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         if (dense_mode == 0 && n >= 48 && map.nLines >= 64) {
             const double *Mm = inverse ? p->Cinv : p->Cfwd;
             dim3 grid((unsigned)((n + MF_KT - 1) / MF_KT), (unsigned)((map.nLines + MF_LT - 1) / MF_LT));
-            if (axis == 0) hipLaunchKernelGGL(k_dct_mfma<true>, grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-            else hipLaunchKernelGGL(k_dct_mfma<false>, grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+            static const int kc = getenv("DOTSOCP_MFMA_KC") ? atoi(getenv("DOTSOCP_MFMA_KC")) : 8;
+            if (kc == 8) {
+                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma<true, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+                else hipLaunchKernelGGL((k_dct_mfma<false, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+            } else {
+                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma<true, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+                else hipLaunchKernelGGL((k_dct_mfma<false, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+            }
             DS_HIP(hipGetLastError());
             return 0;
         }
