@@ -203,9 +203,74 @@ __device__ __forceinline__ void fft_rows_wave(double2 *rows, int lrw, int lg, in
     }
 }
 
+// Decimation-in-time twin of dif_group: same element set (base + m * S/R), the butterflies of spans S/2^(LR-1),
+// ..., S/2, S in INCREASING order with the twiddle applied before the add / subtract -- bit-reversed input,
+// natural-order output.  Used where the spectrum is needed in place in natural order (fused t-axis solve).
+template <int LR>
+__device__ __forceinline__ void dit_group(double2 *__restrict__ row, int sl, int bidx, int lg,
+                                          const double2 *__restrict__ tw) {
+    constexpr int R = 1 << LR;
+    const int strideLog = sl - LR;
+    const int j = bidx & ((1 << strideLog) - 1);
+    const int base = ((bidx >> strideLog) << sl) + j;
+    double2 x[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = row[padi(base + (m << strideLog))];
+    const int tj = j << (lg - sl);   // j * N / S
+#pragma unroll
+    for (int u = LR - 1; u >= 0; --u) {
+        const int hm = R >> (u + 1);
+        const double2 bu = tw[tj << u];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            if ((m / hm) & 1) continue;
+            const int mm = m % hm;
+            const double2 a = x[m];
+            const double2 t = cmul(mul_w16(x[m + hm], (mm << u) * (16 / R)), bu);
+            x[m] = make_double2(a.x + t.x, a.y + t.y);
+            x[m + hm] = make_double2(a.x - t.x, a.y - t.y);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) row[padi(base + (m << strideLog))] = x[m];
+}
+
+// FFT of the calling wave's rows, bit-reversed order in, natural order out (the register groups of
+// fft_rows_wave in reverse order).
+__device__ __forceinline__ void fft_rows_wave_dit(double2 *rows, int lrw, int lg, int rowStride, int lane,
+                                                  const double2 *__restrict__ tw) {
+    const int nst = (lg + 3) >> 2;
+    const int baseBits = lg / nst, extra = lg % nst;
+    int sl = 0;
+    for (int st = nst - 1; st >= 0; --st) {
+        const int lr = baseBits + (st < extra ? 1 : 0);
+        sl += lr;
+        const int lpr = lg - lr;
+        const int total = 1 << (lrw + lpr);
+        for (int b = lane; b < total; b += 64) {
+            double2 *r = rows + (b >> lpr) * rowStride;
+            const int bidx = b & ((1 << lpr) - 1);
+            switch (lr) {
+                case 4: dit_group<4>(r, sl, bidx, lg, tw); break;
+                case 3: dit_group<3>(r, sl, bidx, lg, tw); break;
+                case 2: dit_group<2>(r, sl, bidx, lg, tw); break;
+                default: dit_group<1>(r, sl, bidx, lg, tw); break;
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 // Makhoul reordering v[j] = x[2j], v[n-1-j] = x[2j+1] (mirt_dctn.m:71) -- also the output
 // reordering of the inverse (mirt_idctn.m:71-73,120).
 __device__ __forceinline__ int makhoul(int k, int n) { return (k & 1) ? (n - 1 - (k >> 1)) : (k >> 1); }
+
+// LDS position of input element k while staging a line: forward transforms take the Makhoul order, the inverse
+// the natural one, the fused t-axis solve the bit-reversed Makhoul order (its forward FFT is decimation-in-time)
+template <int MODE>
+__device__ __forceinline__ int stage_pos(int k, int n, int lg) {
+    return MODE == 1 ? k : (MODE == 2 ? bitrev(makhoul(k, n), lg) : makhoul(k, n));
+}
 
 // Inverse pre-processing on the calling wave's rows (natural order, Xa + i Xb elementwise):
 //   G[k] = (ww[k] X[k] + conj(ww[n-k]) X[n-k]) / 2, so that fft(G) = real(fft(ww .* X))
@@ -346,7 +411,6 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
     const int lrw = (lp >= 2) ? lp - 2 : 0;
     const bool waveActive = (wave << lrw) < npairs;
     double2 *rows = lds + (wave << lrw) * rowStride;
-    double2 *bufB = lds + npairs * rowStride;                 // TSOLVE only
     // ---- cooperative load ----
     if (VEC) {
         const int r = tid & (npairs - 1);
@@ -364,7 +428,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
 #pragma unroll
             for (int u = 0; u < DCT_BATCH; ++u) {
                 const int k = k0 + u * kstep;
-                if (k < n) lds[r * rowStride + padi(MODE == 1 ? k : makhoul(k, n))] = gv[u];
+                if (k < n) lds[r * rowStride + padi(stage_pos<MODE>(k, n, lg))] = gv[u];
             }
         }
     } else {
@@ -374,40 +438,77 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
         const i64 lb = ok ? map.base(L) : 0;
         for (int k = tid >> (lp + 1); k < n; k += DCT_THREADS >> (lp + 1)) {
             const double g = ok ? src[lb + (i64)k * map.nin] : 0.0;
-            ((double *)&lds[(l >> 1) * rowStride + padi(MODE == 1 ? k : makhoul(k, n))])[l & 1] = g;
+            ((double *)&lds[(l >> 1) * rowStride + padi(stage_pos<MODE>(k, n, lg))])[l & 1] = g;
         }
     }
     __syncthreads();
     if (waveActive) {
         if (MODE == 1) idct_combine_wave(rows, lrw, lg, rowStride, lane, ww);
-        fft_rows_wave(rows, lrw, lg, rowStride, lane, tw);
-        if (MODE == 2) {
-            // spectral division on the wave's own rows, natural order into the second buffer
-            double2 *rowsB = bufB + (wave << lrw) * rowStride;
-            for (int rr = 0; rr < (1 << lrw); ++rr) {
+        if (MODE != 2) {
+            fft_rows_wave(rows, lrw, lg, rowStride, lane, tw);
+        } else {
+            // forward transform with natural-order output, then -- in place, the lane that owns k also owns n-k --
+            // X = DCT post-processing (dct_post), Y = X / (kscale * lambda), G = inverse pre-processing
+            // (idct_combine_wave) in one go, then the inverse transform on the same rows
+            fft_rows_wave_dit(rows, lrw, lg, rowStride, lane, tw);
+            const int lh = lg - 1;
+            const int total = 1 << (lrw + lh);
+            for (int b = lane; b < total; b += 64) {
+                const int rr = b >> lh;
+                double2 *r = rows + rr * rowStride;
                 i64 La = L0 + 2 * ((wave << lrw) + rr);
                 if (La + 1 >= map.nLines) La = (map.nLines >= 2) ? map.nLines - 2 : 0;
                 const i64 Ga = sa.line0 + La;
                 const i64 Gb = (Ga + 1 < sa.nplane) ? Ga + 1 : Ga;
                 const double ea = sa.cy[Ga % sa.ny] + sa.cx[Ga / sa.ny];                    // CY + CX of line a
                 const double eb = sa.cy[Gb % sa.ny] + sa.cx[Gb / sa.ny];
-                for (int k = lane; k < n; k += 64) {
-                    const double ctk = sa.ct[k];
-                    double la = ea + ctk, lb2 = eb + ctk;
-                    if (la == 0.0) la = 1.0;
-                    if (lb2 == 0.0) lb2 = 1.0;
-                    const double2 X = dct_post(rows + rr * rowStride, k, n, lg, ww);
-                    rowsB[rr * rowStride + padi(k)] = make_double2(X.x / (sa.kscale * la), X.y / (sa.kscale * lb2));
+                const int k = (b & ((1 << lh) - 1)) + 1;          // 1 .. n/2
+                const int m = n - k;
+                const double2 vk = r[padi(k)], vm = r[padi(m)];
+                const double2 wk = ww[k], wm = ww[m];
+                const double ar = 0.5 * (vk.x + vm.x), ai = 0.5 * (vk.y - vm.y);
+                const double br = 0.5 * (vk.y + vm.y), bi = -0.5 * (vk.x - vm.x);
+                const double ctk = sa.ct[k], ctm = sa.ct[m];
+                double lak = ea + ctk, lbk = eb + ctk, lam = ea + ctm, lbm = eb + ctm;
+                if (lak == 0.0) lak = 1.0;
+                if (lbk == 0.0) lbk = 1.0;
+                if (lam == 0.0) lam = 1.0;
+                if (lbm == 0.0) lbm = 1.0;
+                // Y[k], Y[n-k]: .x = line a, .y = line b
+                const double2 xk = make_double2((wk.x * ar - wk.y * ai) / (sa.kscale * lak),
+                                                (wk.x * br - wk.y * bi) / (sa.kscale * lbk));
+                const double2 xm = make_double2((wm.x * ar + wm.y * ai) / (sa.kscale * lam),
+                                                (wm.x * br + wm.y * bi) / (sa.kscale * lbm));
+                const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
+                const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
+                r[padi(k)] = make_double2(gar - gbi, gai + gbr);
+                if (m != k) {
+                    const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
+                    const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
+                    r[padi(m)] = make_double2(har - hbi, hai + hbr);
                 }
             }
+            if (lane < (1 << lrw)) {                               // k = 0: V[0] is its own partner
+                double2 *r = rows + lane * rowStride;
+                i64 La = L0 + 2 * ((wave << lrw) + lane);
+                if (La + 1 >= map.nLines) La = (map.nLines >= 2) ? map.nLines - 2 : 0;
+                const i64 Ga = sa.line0 + La;
+                const i64 Gb = (Ga + 1 < sa.nplane) ? Ga + 1 : Ga;
+                double la = (sa.cy[Ga % sa.ny] + sa.cx[Ga / sa.ny]) + sa.ct[0];
+                double lb2 = (sa.cy[Gb % sa.ny] + sa.cx[Gb / sa.ny]) + sa.ct[0];
+                if (la == 0.0) la = 1.0;
+                if (lb2 == 0.0) lb2 = 1.0;
+                const double w0 = ww[0].x;
+                const double2 v0 = r[0];
+                r[0] = make_double2(w0 * ((w0 * v0.x) / (sa.kscale * la)), w0 * ((w0 * v0.y) / (sa.kscale * lb2)));
+            }
             wave_lds_sync();
-            idct_combine_wave(rowsB, lrw, lg, rowStride, lane, ww);
-            fft_rows_wave(rowsB, lrw, lg, rowStride, lane, tw);
+            fft_rows_wave(rows, lrw, lg, rowStride, lane, tw);
         }
     }
     __syncthreads();
     // ---- cooperative store ----
-    const double2 *out = (MODE == 2) ? bufB : lds;
+    const double2 *out = lds;
     if (VEC) {
         const int r = tid & (npairs - 1);
         const i64 L = L0 + 2 * r;
@@ -889,8 +990,10 @@ static bool dct_wg_enabled() {
 static int launch_strided(int mode, const DctPlan *p, const double *src, double *dst, const LineMap &map,
                           const SolveArgs &sa, hipStream_t st) {
     const int n = (int)p->n, lg = p->log2n;
+    // t-axis solve (two transforms per row, in place): half the rows per workgroup so that twice as many
+    // workgroups are resident
     const int lp = tile_log2_rows(n, map.nLines, mode == 2 ? 2 : 1);
-    const size_t lds = ((size_t)(mode == 2 ? 2 : 1) << lp) * row_stride(n) * sizeof(double2);
+    const size_t lds = ((size_t)1 << lp) * row_stride(n) * sizeof(double2);
     const i64 linesPerBlock = (i64)2 << lp;
     const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
