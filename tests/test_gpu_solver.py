@@ -209,7 +209,12 @@ def test_rccl_communicator_world1(request):
     var, model = D.initialize_slab(rho0, rho1, 16, 0, 16)
     o = OD.default_opts(dict(tol=0.0, maxit=25), "inPALM", False)
     D.InitialScaling(var, model, True, None, dim=2)
-    assert var.D == ref.D and abs(var.cScale - D.initialize(rho0, rho1, 16)[0].phi.size * 0 - var.cScale) == 0
+    # the slab initialisation (||c|| from its two non-zero layers, h from the global node count) must give
+    # exactly the scaling constants of the full-grid one
+    full, fmodel = D.initialize(rho0, rho1, 16)
+    D.InitialScaling(full, fmodel, True, None, dim=2)
+    assert (var.D, var.E, var.cScale, var.dScale) == (full.D, full.E, full.cScale, full.dScale)
+    assert var.D == ref.D
     ctx = D.InPALMContext(var, o, model, rccl=(D.capi.rccl_unique_id(), 0, 1))
     ctx.run(-1)
     hist, sigma = ctx.finish(download=False)
