@@ -29,6 +29,10 @@ struct DctPlan {
     double2 *ww;    // [n]    2 exp(-i pi k / 2n) / sqrt(2n), ww[0] /= sqrt(2)   (mirt_dctn.m:69-70)
     double *Cfwd;   // dense: Cfwd[j*n + k] = C[k][j]   (forward,  out_k = sum_j C[k][j] in_j)
     double *Cinv;   // dense: Cinv[j*n + k] = C[j][k]   (inverse)
+    // even / odd split of the dense matrix (k_dct_mfma_split), [contraction index][output index]:
+    double *Ef, *Of;   // Ef[j*ne + k'] = C[2k'][j] (j < njE), Of[j*no + k'] = C[2k'+1][j] (j < h)
+    double *Ei, *Oi;   // Ei[k'*njE + j] = C[2k'][j],          Oi[k'*h + j]  = C[2k'+1][j]
+    int ne, no, h, njE;
 };
 
 DctPlan *dct_plan_create(i64 n) {
@@ -38,6 +42,8 @@ DctPlan *dct_plan_create(i64 n) {
     p->tw = nullptr;
     p->ww = nullptr;
     p->Cfwd = p->Cinv = nullptr;
+    p->Ef = p->Of = p->Ei = p->Oi = nullptr;
+    p->ne = p->no = p->h = p->njE = 0;
     if (n <= 1) return p;
     const long double PI = 3.141592653589793238462643383279502884L;
     if ((n & (n - 1)) == 0) {
@@ -82,6 +88,25 @@ DctPlan *dct_plan_create(i64 n) {
         }
         (void)hipMemcpy(p->Cfwd, cf.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
         (void)hipMemcpy(p->Cinv, ci.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
+        if (n >= 48) {
+            const int h = (int)(n / 2), ne = (int)((n + 1) / 2), no = (int)(n / 2), njE = h + (int)(n & 1);
+            p->ne = ne; p->no = no; p->h = h; p->njE = njE;
+            auto Cm = [&](i64 k, i64 j) { return cf[(size_t)j * n + k]; };
+            std::vector<double> ef((size_t)njE * ne), of((size_t)h * no), ei((size_t)ne * njE), oi((size_t)no * h);
+            for (int j = 0; j < njE; ++j)
+                for (int k = 0; k < ne; ++k) ef[(size_t)j * ne + k] = ei[(size_t)k * njE + j] = Cm(2 * k, j);
+            for (int j = 0; j < h; ++j)
+                for (int k = 0; k < no; ++k) of[(size_t)j * no + k] = oi[(size_t)k * h + j] = Cm(2 * k + 1, j);
+            double **dst4[4] = {&p->Ef, &p->Of, &p->Ei, &p->Oi};
+            std::vector<double> *src4[4] = {&ef, &of, &ei, &oi};
+            for (int i = 0; i < 4; ++i) {
+                if (hipMalloc(dst4[i], sizeof(double) * src4[i]->size()) != hipSuccess) {
+                    dct_plan_destroy(p);
+                    return nullptr;
+                }
+                (void)hipMemcpy(*dst4[i], src4[i]->data(), sizeof(double) * src4[i]->size(), hipMemcpyHostToDevice);
+            }
+        }
     }
     return p;
 }
@@ -92,6 +117,10 @@ void dct_plan_destroy(DctPlan *p) {
     if (p->ww) (void)hipFree(p->ww);
     if (p->Cfwd) (void)hipFree(p->Cfwd);
     if (p->Cinv) (void)hipFree(p->Cinv);
+    if (p->Ef) (void)hipFree(p->Ef);
+    if (p->Of) (void)hipFree(p->Of);
+    if (p->Ei) (void)hipFree(p->Ei);
+    if (p->Oi) (void)hipFree(p->Oi);
     delete p;
 }
 
@@ -878,6 +907,142 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
             }
 }
 
+
+// Even / odd split of the dense transform: C[k][n-1-j] = (-1)^k C[k][j], so with h = floor(n/2)
+//   forward:  X[2k']   = sum_{j<h} C[2k'][j]   (x[j] + x[n-1-j])  (+ C[2k'][h] x[h] for odd n)
+//             X[2k'+1] = sum_{j<h} C[2k'+1][j] (x[j] - x[n-1-j])
+//   inverse:  E[j] = sum_k' C[2k'][j] X[2k'], O[j] = sum_k' C[2k'+1][j] X[2k'+1],  x[j] = E + O, x[n-1-j] = E - O
+// -- half the multiply-adds of the full product.  Same tiling as k_dct_mfma; the forward kernel forms the sums /
+// differences while staging the lines (parity = blockIdx.z), the inverse kernel keeps two accumulator sets
+// (E, O) per tile of j <= h and writes both mirror images.  Matrices (DctPlan): Ef, Of stored [j][k'] (k'
+// contiguous), Ei, Oi stored [k'][j] (j contiguous) -- always [contraction index][output index].
+struct SplitArgs {
+    const double *Me, *Mo;
+    int ne, no, h, njE;       // even / odd k counts, floor(n/2), h + (n odd ? 1 : 0)
+};
+
+template <bool AXIS0, int MF_KC, bool INV>
+__global__ void __launch_bounds__(256) k_dct_mfma_split(const double *__restrict__ src, double *__restrict__ dst,
+                                                         LineMap map, int n, SplitArgs sp) {
+    constexpr int MF_XZ = MF_KC + 2;
+    constexpr int XSZ = (MF_KC * MF_XS > MF_LT * MF_XZ) ? MF_KC * MF_XS : MF_LT * MF_XZ;
+    constexpr int NPH = INV ? 2 : 1;
+    __shared__ double Ms[2][MF_KC * MF_MS];
+    __shared__ double Xs[2][XSZ];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int o0 = blockIdx.x * MF_KT;                 // first output index of the tile (k' forward, j inverse)
+    const i64 L0 = (i64)blockIdx.y * MF_LT;
+    const int li = lane & 15, lh = lane >> 4;
+    mf_double4 acc[NPH][4][2];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[ph][a][b] = (mf_double4){0.0, 0.0, 0.0, 0.0};
+    constexpr int MU = MF_KC / 4, XU = MF_KC / 2, ZSTEP = 256 / MF_KC;
+    double mreg[MU], xreg[XU];
+    const int m_oo = tid & 63, m_cc = tid >> 6;
+    const int x_ll = AXIS0 ? (tid / MF_KC) : (tid & 127);
+    const int x_cc = AXIS0 ? (tid % MF_KC) : (tid >> 7);
+    i64 xbase = 0;
+    bool x_ok = false;
+    if (!AXIS0) {
+        x_ok = (L0 + x_ll) < map.nLines;
+        xbase = x_ok ? map.base(L0 + x_ll) : 0;
+    }
+    auto at = [&](i64 L, i64 lbase, int j) { return AXIS0 ? src[L * n + j] : src[lbase + (i64)j * map.nin]; };
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        const int par = INV ? ph : (int)blockIdx.z;               // 0: even part, 1: odd part
+        const double *__restrict__ M = par ? sp.Mo : sp.Me;
+        const int ld = INV ? (par ? sp.h : sp.njE) : (par ? sp.no : sp.ne);         // output indices the matrix holds
+        const int ncontr = INV ? (par ? sp.no : sp.ne) : (par ? sp.h : sp.njE);
+        const bool m_ok = (o0 + m_oo) < ld;
+        // the contraction element c of a line: forward x[c] +- x[n-1-c] (the middle one alone), inverse x[2c + par]
+        auto elem = [&](i64 L, i64 lbase, int c) {
+            if (INV) return at(L, lbase, 2 * c + par);
+            if (c >= sp.h) return at(L, lbase, c);                // c == h: middle element of an odd length (even part)
+            const double u = at(L, lbase, c), v = at(L, lbase, n - 1 - c);
+            return par ? u - v : u + v;
+        };
+        auto fetch = [&](int c0) {
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                const int c = c0 + m_cc + 4 * u;
+                mreg[u] = (m_ok && c < ncontr) ? M[(i64)c * ld + o0 + m_oo] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                if (AXIS0) {
+                    const i64 L = L0 + x_ll + ZSTEP * u;
+                    const int c = c0 + x_cc;
+                    xreg[u] = (L < map.nLines && c < ncontr) ? elem(L, 0, c) : 0.0;
+                } else {
+                    const int c = c0 + x_cc + 2 * u;
+                    xreg[u] = (x_ok && c < ncontr) ? elem(0, xbase, c) : 0.0;
+                }
+            }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < MU; ++u) Ms[buf][(m_cc + 4 * u) * MF_MS + m_oo] = mreg[u];
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                if (AXIS0) Xs[buf][(x_ll + ZSTEP * u) * MF_XZ + x_cc] = xreg[u];
+                else Xs[buf][(x_cc + 2 * u) * MF_XS + x_ll] = xreg[u];
+            }
+        };
+        const int nch = (ncontr + MF_KC - 1) / MF_KC;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nch) fetch((c + 1) * MF_KC);
+#pragma unroll
+            for (int kk = 0; kk < MF_KC; kk += 4) {
+                double mf[4], xf[2];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) mf[a] = Ms[buf][(kk + lh) * MF_MS + a * 16 + li];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    xf[b] = AXIS0 ? Xs[buf][(wave * 32 + b * 16 + li) * MF_XZ + kk + lh]
+                                  : Xs[buf][(kk + lh) * MF_XS + wave * 32 + b * 16 + li];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[ph][a][b] = AXIS0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(xf[b], mf[a], acc[ph][a][b], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f64_16x16x4f64(mf[a], xf[b], acc[ph][a][b], 0, 0, 0);
+            }
+            if (c + 1 < nch) stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // ---- store ----
+    const int nout = INV ? sp.njE : (blockIdx.z ? sp.no : sp.ne);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + a * 16 + (AXIS0 ? li : lh + 4 * r);
+                const i64 L = L0 + wave * 32 + b * 16 + (AXIS0 ? lh + 4 * r : li);
+                if (o >= nout || L >= map.nLines) continue;
+                const i64 lbase = AXIS0 ? L * n : map.base(L);
+                const i64 es = AXIS0 ? 1 : map.nin;
+                if (!INV) {
+                    dst[lbase + (i64)(2 * o + (int)blockIdx.z) * es] = acc[0][a][b][r];
+                } else {
+                    const double E = acc[0][a][b][r], O = acc[NPH - 1][a][b][r];
+                    dst[lbase + (i64)o * es] = E + O;
+                    if (o < sp.h) dst[lbase + (i64)(n - 1 - o) * es] = E - O;
+                }
+            }
+}
+
 __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, double *__restrict__ dst, i64 n) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -1127,6 +1292,22 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             const char *e = getenv("DOTSOCP_DENSE");
             return (e && strcmp(e, "rocblas") == 0) ? 1 : ((e && strcmp(e, "kernel") == 0) ? 2 : 0);
         }();
+        static const bool split = !(getenv("DOTSOCP_MFMA_SPLIT") && atoi(getenv("DOTSOCP_MFMA_SPLIT")) == 0);
+        if (dense_mode == 0 && split && p->Ef && map.nLines >= 64) {
+            SplitArgs sp{inverse ? p->Ei : p->Ef, inverse ? p->Oi : p->Of, p->ne, p->no, p->h, p->njE};
+            const unsigned lt = (unsigned)((map.nLines + MF_LT - 1) / MF_LT);
+            if (inverse) {
+                dim3 grid((unsigned)((p->njE + MF_KT - 1) / MF_KT), lt, 1);
+                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma_split<true, 8, true>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+                else hipLaunchKernelGGL((k_dct_mfma_split<false, 8, true>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+            } else {
+                dim3 grid((unsigned)((p->ne + MF_KT - 1) / MF_KT), lt, 2);
+                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma_split<true, 8, false>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+                else hipLaunchKernelGGL((k_dct_mfma_split<false, 8, false>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+            }
+            DS_HIP(hipGetLastError());
+            return 0;
+        }
         if (dense_mode == 0 && n >= 48 && map.nLines >= 64) {
             const double *Mm = inverse ? p->Cinv : p->Cfwd;
             dim3 grid((unsigned)((n + MF_KT - 1) / MF_KT), (unsigned)((map.nLines + MF_LT - 1) / MF_LT));
