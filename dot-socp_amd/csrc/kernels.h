@@ -142,6 +142,13 @@ int launch_qstep(const Grid &g, const LoopCoef &c, const double *phi, const doub
 int launch_u0_tail(const Grid &g, const double *q, const double *alpha, const double *weight, double *out,
                    hipStream_t st);
 int launch_scale(double *x, i64 n, double mul, double div, hipStream_t st);   // x = x * mul / div
+// slab rows <-> per-peer contiguous staging of the slab <-> pencil transposes (one process per slab)
+#define DS_MAX_WORLD 64
+struct PencilCuts {
+    int world;
+    i64 cut[DS_MAX_WORLD + 1];
+};
+int launch_pencil_pack(bool pack, const PencilCuts &pc, i64 plane, i64 ntl, double *slab, double *stage, hipStream_t st);
 
 // ---------------- kkt.hip ----------------
 struct KktWork {

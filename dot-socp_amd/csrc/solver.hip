@@ -205,6 +205,7 @@ int Solver::alloc_slabs(int first, int count) {
 int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     DS_ARG(id != nullptr, "unique id is NULL");
     DS_ARG(wd >= 1 && rk >= 0 && rk < wd, "bad rank / world");
+    DS_ARG(wd <= DS_MAX_WORLD, "at most 64 slabs");
     DS_ARG(wd <= nt / 2, "world must not exceed nt/2 time slabs");
     if (begun || world != 1 || !slabs.empty()) {
         set_error("attach_rccl() must directly follow create(..., nslabs = 1)");
@@ -308,27 +309,38 @@ int Solver::transpose(bool forward) {
             }
         return 0;
     }
-    // one slab per process: pack the part of every peer contiguously, then one send/recv per peer
+    // one slab per process: pack the part of every peer contiguously (one kernel), then one send/recv per peer;
+    // the own part is a plain device copy
     Rccl &api = rccl_api();
     Slab &s = slabs[0];
     std::vector<i64> off(world + 1, 0), pl0(world), pnl(world), pt0(world), pntl(world);
+    PencilCuts pc{};
+    pc.world = world;
     for (int j = 0; j < world; ++j) {
         i64 a, b;
         pencil_range(plane, world, j, &a, &b);
         pl0[j] = a;
         pnl[j] = b - a;
+        pc.cut[j] = a;
+        pc.cut[j + 1] = b;
         dotsocp_slab_range_impl(nt, world, j, &a, &b);
         pt0[j] = a;
         pntl[j] = b - a;
         off[j + 1] = off[j] + pnl[j] * s.g.ntl;
     }
+    auto self_copy = [&](bool fwd) -> int {
+        if (s.nl <= 0) return 0;
+        double *st_ = s.stage + off[rank], *pe = s.pencil + s.nl * pt0[rank];
+        const size_t bytes = sizeof(double) * (size_t)(s.nl * s.g.ntl);
+        DS_HIP(hipMemcpyAsync(fwd ? pe : st_, fwd ? st_ : pe, bytes, hipMemcpyDeviceToDevice, stream));
+        return 0;
+    };
     if (forward) {
-        for (int j = 0; j < world; ++j)
-            if (pnl[j] > 0)
-                DS_HIP(hipMemcpy2DAsync(s.stage + off[j], sizeof(double) * pnl[j], s.w0 + pl0[j], sizeof(double) * plane,
-                                        sizeof(double) * pnl[j], s.g.ntl, hipMemcpyDeviceToDevice, stream));
+        DS_CHECK(launch_pencil_pack(true, pc, plane, s.g.ntl, s.w0, s.stage, stream));
+        DS_CHECK(self_copy(true));
         DS_NCCL(api.GroupStart());
         for (int j = 0; j < world; ++j) {
+            if (j == rank) continue;
             if (pnl[j] > 0)
                 DS_NCCL(api.Send(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
             if (s.nl > 0)
@@ -336,18 +348,17 @@ int Solver::transpose(bool forward) {
         }
         DS_NCCL(api.GroupEnd());
     } else {
+        DS_CHECK(self_copy(false));
         DS_NCCL(api.GroupStart());
         for (int j = 0; j < world; ++j) {
+            if (j == rank) continue;
             if (s.nl > 0)
                 DS_NCCL(api.Send(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
             if (pnl[j] > 0)
                 DS_NCCL(api.Recv(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
         }
         DS_NCCL(api.GroupEnd());
-        for (int j = 0; j < world; ++j)
-            if (pnl[j] > 0)
-                DS_HIP(hipMemcpy2DAsync(s.w0 + pl0[j], sizeof(double) * plane, s.stage + off[j], sizeof(double) * pnl[j],
-                                        sizeof(double) * pnl[j], s.g.ntl, hipMemcpyDeviceToDevice, stream));
+        DS_CHECK(launch_pencil_pack(false, pc, plane, s.g.ntl, s.w0, s.stage, stream));
     }
     return 0;
 }
@@ -829,10 +840,12 @@ int Solver::kkt_sums(double *S) {
             if (!s.g.last)
                 DS_CHECK(launch_kkt_tail(s.g, s.alpha, s.beta, s.weight, s.send_plane, s.send_plane2, s.send_bx, s.send_by,
                                          stream));
+        DS_CHECK(group_begin());
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.a0_prev; }, plane));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane2; }, [](Slab &s) { return s.a0w_prev; }, plane));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_bx; }, [](Slab &s) { return s.btail_bx; }, slabs[0].g.bxLayer));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.btail_by; }, slabs[0].g.byLayer));
+        DS_CHECK(group_end());
     }
     for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
     for (auto &s : slabs) {

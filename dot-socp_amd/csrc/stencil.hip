@@ -572,6 +572,33 @@ int launch_kkt_tail(const Grid &g, const double *alpha, const double *beta, cons
     return 0;
 }
 
+// One-process-per-slab transposes of the Poisson solve: the slab rows [t][col] <-> the send / receive staging
+// area in which the columns of every peer's pencil are contiguous, [peer][t][col - cut(peer)], in ONE launch
+// (cut[j] .. cut[j+1] are the columns of pencil j; the area of peer j starts at cut[j] * ntl).
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_pencil_pack(PencilCuts pc, i64 plane, i64 ntl, double *__restrict__ slab,
+                                                      double *__restrict__ stage) {
+    const i64 col = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 t = blockIdx.y;
+    if (col >= plane) return;
+    int j = (int)((col * pc.world) / plane);                 // first guess, then walk to the owning pencil
+    while (j > 0 && col < pc.cut[j]) --j;
+    while (j < pc.world - 1 && col >= pc.cut[j + 1]) ++j;
+    const i64 c0 = pc.cut[j], w = pc.cut[j + 1] - c0;
+    const i64 si = c0 * ntl + t * w + (col - c0);
+    if (PACK) stage[si] = slab[t * plane + col];
+    else slab[t * plane + col] = stage[si];
+}
+
+int launch_pencil_pack(bool pack, const PencilCuts &pc, i64 plane, i64 ntl, double *slab, double *stage, hipStream_t st) {
+    if (plane * ntl <= 0) return 0;
+    dim3 grid((unsigned)((plane + 255) / 256), (unsigned)ntl);
+    if (pack) hipLaunchKernelGGL(k_pencil_pack<true>, grid, dim3(256), 0, st, pc, plane, ntl, slab, stage);
+    else hipLaunchKernelGGL(k_pencil_pack<false>, grid, dim3(256), 0, st, pc, plane, ntl, slab, stage);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
 // x = x * mul / div  (left to right, like `alpha * dScale2 / cScale2^2`, solver_socp_inPALM.m:170-178,312-314)
 __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, i64 n, double mul, double div, int use_mul) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
