@@ -116,11 +116,13 @@ int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, cons
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
                      double *rhs, hipStream_t st);
+// acc-ADMM: q-step + multiplier + next rhs (var 1: raw q^+, alpha^+; var 2: raw q^+ plus the Halpern step of q in
+// place in q_state and of alpha into alpha_out, buffers other than alpha_in)
+int launch_qstep_rhs_acc(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi,
+                         const double *q2, const double *sx, const double *sy, const double *weight, const double *cvec,
+                         double *q_raw, const double *alpha_in, double *alpha_out, double *rhs, double *q_state,
+                         const double *q_anchor, const double *alpha_anchor, const AccCoef &k, hipStream_t st);
 int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, double *rhs, hipStream_t st);
-// acc-ADMM flavour (solver_socp_accADMM.m:229-237): same q, alpha_out = (alpha_in + A phi) - w.*q
-int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
-                     const double *sx, const double *sy, const double *weight, double *q_out,
-                     const double *alpha_in, double *alpha_out, hipStream_t st);
 // PALM (solver_socp_PALM.m:196-200,137): first q-step without the alpha update; tmp_q = A phi in q layout
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                             const double *sx, const double *sy, double *q_out, const double *alpha, hipStream_t st);

@@ -8,12 +8,13 @@
 // Device dataflow.  At the top of an iteration the "Old" copies of the reference equal the current
 // state, so only the state x, the outputs x^+ and the anchors x0 (Halpern) or previous extrapolation
 // points (theta != 2) are kept.  Per iteration:
-//   q-step      q^+, alpha^+  <- phi, alpha, q2 = F*B*(z + beta)            k_qstep_fused<ACC>   (:227-237)
+//   q-step      q^+, alpha^+, rhs of the phi-step <- phi, alpha, q2 = F*B*(z + beta)   k_qstep_rhs<.,1|2>  (:227-237,243)
+//               without a KKT check (Halpern): extrapolation of q and alpha in the same pass
 //   cone pass   beta^+, z^+   <- z, beta, q^+                               k_acc_cone           (:236-249)
 //               without a KKT check (Halpern): extrapolation of z, beta and the NEXT iteration's q2 in the same pass
-//   phi-step    phi^+         <- q^+, alpha^+                               rhs + DCT Poisson    (:241-244)
+//   phi-step    phi^+         <- rhs                                        DCT Poisson          (:241-244)
 //   [KKT block at x^+]
-//   extrapolation of phi, q, alpha (and of z, beta when not folded)         k_acc_interp         (:369-423)
+//   extrapolation of phi (and of q, alpha, z, beta when not folded)         k_acc_interp         (:369-423)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -178,9 +179,19 @@ int Solver::acc_step(bool *brk) {
         }
         prof_end(PH_ACC_GATHER);
     }
+    // q^+ (raw, for the cone pass and the KKT block) always goes to q_old and the right-hand side of the phi-step
+    // to w0; without a KKT check the Halpern step of q (in place) and alpha (ping-pong) is part of the same pass
     prof_begin(PH_QSTEP);
-    for (auto &s : slabs)
-        DS_CHECK(launch_qstep_acc(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.q_old, s.alpha, s.alpha_p, stream));
+    for (auto &s : slabs) {
+        if (fold) {
+            DS_CHECK(launch_qstep_rhs_acc(2, s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.c, s.q_old, s.alpha,
+                                          s.alpha2, s.w0, s.q, s.q_a, s.alpha_a, kc, stream));
+            std::swap(s.alpha, s.alpha2);
+        } else {
+            DS_CHECK(launch_qstep_rhs_acc(1, s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.c, s.q_old, s.alpha,
+                                          s.alpha_p, s.w0, nullptr, nullptr, nullptr, kc, stream));
+        }
+    }
     prof_end(PH_QSTEP);
 
     // ---- multipliers + step z (:234-239,246-249); the cone pass does not need phi^+ ----
@@ -200,9 +211,6 @@ int Solver::acc_step(bool *brk) {
     prof_end(PH_ACC_CONE);
 
     // ---- step phi (:241-244) ----
-    prof_begin(PH_RHS);
-    for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q_old, s.alpha_p, s.c, s.weight, nullptr, s.w0, stream));
-    prof_end(PH_RHS);
     prof_begin(PH_POISSON);
     for (auto &s : slabs) std::swap(s.phi, s.phi_p);      // poisson_all() writes s.phi
     int rc = poisson_all();
@@ -226,8 +234,10 @@ int Solver::acc_step(bool *brk) {
     for (auto &s : slabs) {
         const Grid &g = s.g;
         DS_CHECK(launch_acc_interp(s.phi, s.phi_p, s.phi_a, g.Nphi, k2, mode, write_aux, stream));
-        DS_CHECK(launch_acc_interp(s.q, s.q_old, s.q_a, g.NqAlloc, k2, mode, write_aux, stream));
-        DS_CHECK(launch_acc_interp(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, mode, write_aux, stream));
+        if (!fold) {
+            DS_CHECK(launch_acc_interp(s.q, s.q_old, s.q_a, g.NqAlloc, k2, mode, write_aux, stream));
+            DS_CHECK(launch_acc_interp(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, mode, write_aux, stream));
+        }
         if (fold) {
             std::swap(s.z, s.z_p);                         // the cone pass wrote the new state there
             std::swap(s.beta, s.beta2);

@@ -277,33 +277,51 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
 //   one of rhs_value().  Time-slab mode: the term of the left neighbour's last cell is added by k_rhs_fixup
 //   after the u0 exchange.
 // ---------------------------------------------------------------------------------------
-template <bool WEIGHTED>
-__device__ __forceinline__ void q_value(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
-                                        const double *__restrict__ weight, const double *__restrict__ alpha_in,
-                                        double &qn, double &an, double &u) {
+template <bool WEIGHTED, bool ACC = false>
+__device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
+                                          const double *__restrict__ weight, const double *__restrict__ alpha_in,
+                                          double &qn, double &an, double &u) {
     const double a = alpha_in[k];
     if (WEIGHTED) {
         const double w = weight[k];
         const double di = 1.0 / (diag_c + w * w);
         qn = (w * (tmp + a) + q2) * di;
-        const double r = tmp - w * qn;
-        an = a + c.tau * r;
+        if (ACC) {
+            const double t = a + tmp;                 // alpha + tmp_q - w.*q (solver_wsocp_accADMM.m:243)
+            an = t - w * qn;
+        } else {
+            const double r = tmp - w * qn;
+            an = a + c.tau * r;
+        }
         u = w * qn - an;
     } else {
         qn = (tmp + a + q2) * dinv;
-        const double r = tmp - qn;
-        an = a + c.tau * r;
+        if (ACC) {
+            const double t = a + tmp;                 // alpha + tmp_q - q (solver_socp_accADMM.m:237)
+            an = t - qn;
+        } else {
+            const double r = tmp - qn;
+            an = a + c.tau * r;
+        }
         u = qn - an;
     }
+    return a;
 }
 
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
     i64 TC;
+    // VAR 2 (acc-ADMM, Halpern step folded in): q_out receives the raw q^+ (the cone pass needs it), the
+    // extrapolated q goes to q_state in place and the extrapolated alpha to alpha_out
+    double *q_state;
+    const double *q_anchor, *alpha_anchor;
+    double c1, c2, om_rho, rho;
 };
 
-template <bool WEIGHTED>
+// VAR 0: inPALM / ALG2; 1: acc-ADMM multiplier arithmetic, raw outputs; 2: acc-ADMM with the Halpern step of q and
+// alpha folded in (solver_socp_accADMM.m:373-379); the rhs is formed from the raw u = w.*q^+ - alpha^+ in all cases
+template <bool WEIGHTED, int VAR>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
     __shared__ double xch[2][TILE_X][TILE_Y];
     const int lane = threadIdx.x, xl = threadIdx.y;
@@ -324,6 +342,19 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
         if (tl == 0 && !g.first) q2 += a.tail_by[yy + (g.ny - 1) * xx];
         return q2;
     };
+    auto put = [&](i64 k, double qn, double an, double ain) {
+        a.q_out[k] = qn;
+        if (VAR == 2) {
+            double t = a.om_rho * a.q_state[k];
+            t = t + a.rho * qn;
+            a.q_state[k] = a.c1 * a.q_anchor[k] + a.c2 * t;
+            t = a.om_rho * ain;
+            t = t + a.rho * an;
+            a.alpha_out[k] = a.c1 * a.alpha_anchor[k] + a.c2 * t;
+        } else {
+            a.alpha_out[k] = an;
+        }
+    };
     double u0prev = 0.0;
     double p0 = 0.0;
     if (inb) {
@@ -334,7 +365,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
             double tmp = (-c.at) * a.phi[k];
             tmp += c.at * p0;
             double qn, an;
-            q_value<WEIGHTED>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev);
+            q_value<WEIGHTED, VAR != 0>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev);
         }
     }
     int par = 0;
@@ -350,25 +381,22 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 pT = a.phi[node + g.plane];
                 double tmp = (-c.at) * p0;
                 tmp += c.at * pT;
-                q_value<WEIGHTED>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
-                a.q_out[node] = qn;
-                a.alpha_out[node] = an;
+                const double ain = q_value<WEIGHTED, VAR != 0>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
+                put(node, qn, an, ain);
             }
             if (x < g.nx - 1) {
                 const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
                 double tmp = (-c.ax) * p0;
                 tmp += c.ax * a.phi[node + g.ny];
-                q_value<WEIGHTED>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx);
-                a.q_out[e] = qn;
-                a.alpha_out[e] = an;
+                const double ain = q_value<WEIGHTED, VAR != 0>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx);
+                put(e, qn, an, ain);
             }
             if (y < g.ny - 1) {
                 const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
                 double tmp = (-c.ay) * p0;
                 tmp += c.ay * a.phi[node + 1];
-                q_value<WEIGHTED>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby);
-                a.q_out[e] = qn;
-                a.alpha_out[e] = an;
+                const double ain = q_value<WEIGHTED, VAR != 0>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby);
+                put(e, qn, an, ain);
             }
         }
         xch[par][xl][lane] = ubx;
@@ -384,7 +412,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                     double tmp = (-c.ax) * a.phi[node - g.ny];
                     tmp += c.ax * p0;
                     double qn, an;
-                    q_value<WEIGHTED>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m);
+                    q_value<WEIGHTED, VAR != 0>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m);
                 }
             }
             if (y >= 1 && lane == 0) {      // edge owned by the tile below
@@ -392,7 +420,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 double tmp = (-c.ay) * a.phi[node - 1];
                 tmp += c.ay * p0;
                 double qn, an;
-                q_value<WEIGHTED>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m);
+                q_value<WEIGHTED, VAR != 0>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m);
             }
             double r = 0.0;
             if (tl >= 1) r += c.at * u0prev;
@@ -409,11 +437,32 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     }
 }
 
+static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st);
+
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
                      double *rhs, hipStream_t st) {
-    QRhsArgs a{phi, q2, sx, sy, weight, tail_bx, tail_by, cvec, alpha_in, q_out, alpha_out, rhs, 0};
+    QRhsArgs a{};
+    a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.weight = weight; a.tail_bx = tail_bx; a.tail_by = tail_by;
+    a.cvec = cvec; a.alpha_in = alpha_in; a.q_out = q_out; a.alpha_out = alpha_out; a.rhs = rhs;
+    return launch_qstep_rhs_var(0, g, c, fg, a, st);
+}
+
+// var 1 / 2: the acc-ADMM flavours (see k_qstep_rhs); `acc` carries the Halpern weights and the extra arrays of var 2
+int launch_qstep_rhs_acc(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi,
+                         const double *q2, const double *sx, const double *sy, const double *weight, const double *cvec,
+                         double *q_raw, const double *alpha_in, double *alpha_out, double *rhs, double *q_state,
+                         const double *q_anchor, const double *alpha_anchor, const AccCoef &k, hipStream_t st) {
+    QRhsArgs a{};
+    a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.weight = weight; a.cvec = cvec;
+    a.alpha_in = alpha_in; a.q_out = q_raw; a.alpha_out = alpha_out; a.rhs = rhs;
+    a.q_state = q_state; a.q_anchor = q_anchor; a.alpha_anchor = alpha_anchor;
+    a.c1 = k.c1; a.c2 = k.c2; a.om_rho = k.om_rho; a.rho = k.rho;
+    return launch_qstep_rhs_var(var, g, c, fg, a, st);
+}
+
+static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st) {
     // short chunks of time layers (measured at 1024x1024x128: 3.45 ms with 8-layer chunks, 4.2 ms with one chunk per
     // tile -- the march is latency-bound per workgroup); each extra chunk recomputes one cell
     const i64 tiles = fg.nyblk * fg.nxblk;
@@ -425,8 +474,13 @@ int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, cons
     a.TC = TC;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)((g.ntl + TC - 1) / TC));
     dim3 blk(TILE_Y, TILE_X);
-    if (weight) hipLaunchKernelGGL(k_qstep_rhs<true>, grid, blk, 0, st, g, c, fg, a);
-    else hipLaunchKernelGGL(k_qstep_rhs<false>, grid, blk, 0, st, g, c, fg, a);
+#define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
+    if (a.weight) {
+        if (var == 0) QRHS_LAUNCH(true, 0); else if (var == 1) QRHS_LAUNCH(true, 1); else QRHS_LAUNCH(true, 2);
+    } else {
+        if (var == 0) QRHS_LAUNCH(false, 0); else if (var == 1) QRHS_LAUNCH(false, 1); else QRHS_LAUNCH(false, 2);
+    }
+#undef QRHS_LAUNCH
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -443,21 +497,6 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs_fixup(Grid g, double at,
 
 int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, double *rhs, hipStream_t st) {
     hipLaunchKernelGGL(k_rhs_fixup, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c.at, u0_prev, rhs);
-    DS_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_qstep_acc(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
-                     const double *sx, const double *sy, const double *weight, double *q_out, const double *alpha_in,
-                     double *alpha_out, hipStream_t st) {
-    dim3 blk(TILE_Y, TILE_X);
-    const double *none = nullptr;
-    if (weight)
-        hipLaunchKernelGGL((k_qstep_fused<true, 3, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
-                           weight, none, none, q_out, alpha_out, alpha_in);
-    else
-        hipLaunchKernelGGL((k_qstep_fused<false, 3, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy,
-                           weight, none, none, q_out, alpha_out, alpha_in);
     DS_HIP(hipGetLastError());
     return 0;
 }
