@@ -15,6 +15,7 @@
 //   beta^{k+1}: deferred to pass 1 of the next iteration (or to the KKT block)              (:222-226)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "solver.h"
 
@@ -64,12 +65,9 @@ int Solver::palm_step(bool *brk) {
         }
     }
     for (auto &s : slabs)
-        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.q_old, s.alpha, stream));
+        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, stream));
     prof_end(PH_QSTEP0);
-    // ---- step phi :202-205 ----
-    prof_begin(PH_RHS);
-    for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q_old, s.alpha, s.c, nullptr, nullptr, s.w0, stream));
-    prof_end(PH_RHS);
+    // ---- step phi :202-205 (its right-hand side was formed by the q-step above) ----
     prof_begin(PH_POISSON);
     DS_CHECK(poisson_all());
     prof_end(PH_POISSON);

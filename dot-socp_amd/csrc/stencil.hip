@@ -277,7 +277,8 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
 //   one of rhs_value().  Time-slab mode: the term of the left neighbour's last cell is added by k_rhs_fixup
 //   after the u0 exchange.
 // ---------------------------------------------------------------------------------------
-template <bool WEIGHTED, bool ACC = false>
+// MULT 0: alpha + tau (A phi - w q) (inPALM); 1: (alpha + A phi) - w q (acc-ADMM); 2: alpha stays (PALM's first q-step)
+template <bool WEIGHTED, int MULT = 0>
 __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
                                           const double *__restrict__ weight, const double *__restrict__ alpha_in,
                                           double &qn, double &an, double &u) {
@@ -286,7 +287,9 @@ __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double 
         const double w = weight[k];
         const double di = 1.0 / (diag_c + w * w);
         qn = (w * (tmp + a) + q2) * di;
-        if (ACC) {
+        if (MULT == 2) {
+            an = a;
+        } else if (MULT == 1) {
             const double t = a + tmp;                 // alpha + tmp_q - w.*q (solver_wsocp_accADMM.m:243)
             an = t - w * qn;
         } else {
@@ -296,7 +299,9 @@ __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double 
         u = w * qn - an;
     } else {
         qn = (tmp + a + q2) * dinv;
-        if (ACC) {
+        if (MULT == 2) {
+            an = a;
+        } else if (MULT == 1) {
             const double t = a + tmp;                 // alpha + tmp_q - q (solver_socp_accADMM.m:237)
             an = t - qn;
         } else {
@@ -320,7 +325,8 @@ struct QRhsArgs {
 };
 
 // VAR 0: inPALM / ALG2; 1: acc-ADMM multiplier arithmetic, raw outputs; 2: acc-ADMM with the Halpern step of q and
-// alpha folded in (solver_socp_accADMM.m:373-379); the rhs is formed from the raw u = w.*q^+ - alpha^+ in all cases
+// alpha folded in (solver_socp_accADMM.m:373-379); 3: PALM's first q-step (q only, solver_socp_PALM.m:196-200).
+// The rhs is formed from the raw u = w.*q^+ - alpha^+ in all cases (VAR 3: alpha^+ = alpha)
 template <bool WEIGHTED, int VAR>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
     __shared__ double xch[2][TILE_X][TILE_Y];
@@ -344,6 +350,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     };
     auto put = [&](i64 k, double qn, double an, double ain) {
         a.q_out[k] = qn;
+        if (VAR == 3) return;                         // PALM's first q-step: alpha is not touched
         if (VAR == 2) {
             double t = a.om_rho * a.q_state[k];
             t = t + a.rho * qn;
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
             double tmp = (-c.at) * a.phi[k];
             tmp += c.at * p0;
             double qn, an;
-            q_value<WEIGHTED, VAR != 0>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev);
+            q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev);
         }
     }
     int par = 0;
@@ -381,21 +388,21 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 pT = a.phi[node + g.plane];
                 double tmp = (-c.at) * p0;
                 tmp += c.at * pT;
-                const double ain = q_value<WEIGHTED, VAR != 0>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
+                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
                 put(node, qn, an, ain);
             }
             if (x < g.nx - 1) {
                 const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
                 double tmp = (-c.ax) * p0;
                 tmp += c.ax * a.phi[node + g.ny];
-                const double ain = q_value<WEIGHTED, VAR != 0>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx);
+                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx);
                 put(e, qn, an, ain);
             }
             if (y < g.ny - 1) {
                 const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
                 double tmp = (-c.ay) * p0;
                 tmp += c.ay * a.phi[node + 1];
-                const double ain = q_value<WEIGHTED, VAR != 0>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby);
+                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby);
                 put(e, qn, an, ain);
             }
         }
@@ -412,7 +419,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                     double tmp = (-c.ax) * a.phi[node - g.ny];
                     tmp += c.ax * p0;
                     double qn, an;
-                    q_value<WEIGHTED, VAR != 0>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m);
+                    q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m);
                 }
             }
             if (y >= 1 && lane == 0) {      // edge owned by the tile below
@@ -420,7 +427,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 double tmp = (-c.ay) * a.phi[node - 1];
                 tmp += c.ay * p0;
                 double qn, an;
-                q_value<WEIGHTED, VAR != 0>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m);
+                q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m);
             }
             double r = 0.0;
             if (tl >= 1) r += c.at * u0prev;
@@ -478,7 +485,8 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     if (a.weight) {
         if (var == 0) QRHS_LAUNCH(true, 0); else if (var == 1) QRHS_LAUNCH(true, 1); else QRHS_LAUNCH(true, 2);
     } else {
-        if (var == 0) QRHS_LAUNCH(false, 0); else if (var == 1) QRHS_LAUNCH(false, 1); else QRHS_LAUNCH(false, 2);
+        if (var == 0) QRHS_LAUNCH(false, 0); else if (var == 1) QRHS_LAUNCH(false, 1);
+        else if (var == 2) QRHS_LAUNCH(false, 2); else QRHS_LAUNCH(false, 3);
     }
 #undef QRHS_LAUNCH
     DS_HIP(hipGetLastError());
@@ -501,14 +509,15 @@ int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, do
     return 0;
 }
 
-// PALM's first q-step (solver_socp_PALM.m:196-200): q_out = (A phi + alpha + q2) .* diagQInv, alpha untouched
+// PALM's first q-step (solver_socp_PALM.m:196-200): q_out = (A phi + alpha + q2) .* diagQInv, alpha untouched,
+// plus the rhs of the phi-step that follows it (:204), A'(q_out - alpha) + c
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
-                            const double *sx, const double *sy, double *q_out, const double *alpha, hipStream_t st) {
-    const double *none = nullptr;
-    hipLaunchKernelGGL((k_qstep_fused<false, 3, 2>), tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, fg, phi, q2,
-                       sx, sy, none, none, none, q_out, const_cast<double *>(alpha), none);
-    DS_HIP(hipGetLastError());
-    return 0;
+                            const double *sx, const double *sy, const double *cvec, double *q_out, const double *alpha,
+                            double *rhs, hipStream_t st) {
+    QRhsArgs a{};
+    a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.cvec = cvec;
+    a.alpha_in = alpha; a.q_out = q_out; a.rhs = rhs;
+    return launch_qstep_rhs_var(3, g, c, fg, a, st);
 }
 
 // tmp_q = A phi in q layout (solver_socp_PALM.m:137): forward differences times D/h, like the q-step
