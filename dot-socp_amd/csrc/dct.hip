@@ -1159,6 +1159,10 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     // workgroups are resident
     const int lp = tile_log2_rows(n, map.nLines, mode == 2 ? 2 : 1);
     const size_t lds = ((size_t)1 << lp) * row_stride(n) * sizeof(double2);
+    if (lds > DCT_LDS_MAX) {
+        set_error("power-of-two DCT length %d does not fit the LDS (largest supported: 8192)", n);
+        return DOTSOCP_EINVAL;
+    }
     const i64 linesPerBlock = (i64)2 << lp;
     const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
@@ -1256,6 +1260,11 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         int lp = tile_log2_rows((int)n, map.nLines, 1);
         const int lrw = lp >= 2 ? lp - 2 : 0;
         const size_t lds = ((size_t)DCT_WAVES << lrw) * row_stride((int)n) * sizeof(double2);
+        if (lds > DCT_LDS_MAX) {
+            set_error("power-of-two DCT length %lld does not fit the LDS (largest supported: 2048 along y, 8192 along x / t)",
+                      (long long)n);
+            return DOTSOCP_EINVAL;
+        }
         const i64 linesPerBlock = (i64)(2 * DCT_WAVES) << lrw;
         const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
         static bool once = false;
