@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch ships its own copy of the HIP runtime; whichever copy is loaded first serves the whole process.  The
+# full-size tests keep their data in torch tensors next to libdotsocp calls, so torch has to come first (as in
+# bench.py): loaded after libdotsocp it finds "no ROCm-capable device".
+try:
+    import torch  # noqa: F401
+except Exception:       # noqa: BLE001
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
