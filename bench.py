@@ -231,7 +231,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "ADMM iters/sec on NxNxT dot2d staggered grid",
+        "metric": "ADMM iters/sec on NxNxT dot2d staggered grid at 1/2/4/8 MI355X",
         "value": args.steps / dt,
         "unit": "iterations/s",
         "n_gpus": world,
