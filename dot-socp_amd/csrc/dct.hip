@@ -919,6 +919,7 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
 struct SplitArgs {
     const double *Me, *Mo;
     int ne, no, h, njE;       // even / odd k counts, floor(n/2), h + (n odd ? 1 : 0)
+    int xcd;                  // XCD-aware tile order
 };
 
 template <bool AXIS0, int MF_KC, bool INV>
@@ -930,8 +931,12 @@ __global__ void __launch_bounds__(256) k_dct_mfma_split(const double *__restrict
     __shared__ double Ms[2][MF_KC * MF_MS];
     __shared__ double Xs[2][XSZ];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int o0 = blockIdx.x * MF_KT;                 // first output index of the tile (k' forward, j inverse)
-    const i64 L0 = (i64)blockIdx.y * MF_LT;
+    // the output tiles that share a line tile run back to back on ONE XCD (xcd_tile), so that the lines come
+    // from that XCD's L2 for all but the first of them
+    const i64 P = sp.xcd ? xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y)
+                         : (i64)blockIdx.x + (i64)gridDim.x * blockIdx.y;
+    const int o0 = (int)(P % gridDim.x) * MF_KT;       // first output index of the tile (k' forward, j inverse)
+    const i64 L0 = (P / gridDim.x) * MF_LT;
     const int li = lane & 15, lh = lane >> 4;
     mf_double4 acc[NPH][4][2];
 #pragma unroll
@@ -1303,7 +1308,8 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         }();
         static const bool split = !(getenv("DOTSOCP_MFMA_SPLIT") && atoi(getenv("DOTSOCP_MFMA_SPLIT")) == 0);
         if (dense_mode == 0 && split && p->Ef && map.nLines >= 64) {
-            SplitArgs sp{inverse ? p->Ei : p->Ef, inverse ? p->Oi : p->Of, p->ne, p->no, p->h, p->njE};
+            static const int mfma_xcd = getenv("DOTSOCP_MFMA_XCD") ? atoi(getenv("DOTSOCP_MFMA_XCD")) : 1;
+            SplitArgs sp{inverse ? p->Ei : p->Ef, inverse ? p->Oi : p->Of, p->ne, p->no, p->h, p->njE, mfma_xcd};
             const unsigned lt = (unsigned)((map.nLines + MF_LT - 1) / MF_LT);
             if (inverse) {
                 dim3 grid((unsigned)((p->njE + MF_KT - 1) / MF_KT), lt, 1);
