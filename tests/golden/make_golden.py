@@ -60,16 +60,16 @@ def operators():
     np.savez_compressed(os.path.join(HERE, "operators.npz"), **out)
 
 
-def trajectory(name, rho0, rho1, nt, K, weight=None, method="inPALM"):
-    var, model, o = OD.make_level(rho0, rho1, nt, dict(tol=0.0, maxit=K), method, weight)
-    st = InPALMState(var, o, model, weighted=weight is not None)
+def trajectory(name, rho0, rho1, nt, K, weight=None, method="inPALM", **extra_opts):
+    var, model, o = OD.make_level(rho0, rho1, nt, dict(tol=0.0, maxit=K, **extra_opts), method, weight)
+    st = OD.make_state(var, o, model, method, weighted=weight is not None)
     st.run()
     hist, sigma = st.finish()
     extra = {} if weight is None else {"weight": weight}
     np.savez_compressed(os.path.join(HERE, name + ".npz"), rho0=rho0, rho1=rho1, nt=nt, K=K,
                         phi=var.phi, q=var.q, alpha=var.alpha, z=var.z, beta=var.beta, sigma=sigma,
                         kkt=hist["kkt"], iters=hist["iter"], pdGap=hist["pdGap"], cScale=var.cScale,
-                        dScale=var.dScale, method=method, **extra)
+                        dScale=var.dScale, method=method, **{"opt_" + k: v for k, v in extra_opts.items()}, **extra)
 
 
 if __name__ == "__main__":
@@ -86,4 +86,12 @@ if __name__ == "__main__":
     w = get_weight_by_barrier(16, 16, 8, b)
     r0, r1, _ = ensure_barrier_validity(r0, r1, b)
     trajectory("traj_wdot2d_16x16x8", r0, r1, 8, 30, weight=w)
+    # loop variants
+    r0, r1 = get_example_2d("example1", 16, 12)
+    trajectory("traj_palm_16x12x8", r0, r1, 8, 25, method="PALM")
+    trajectory("traj_accadmm_16x12x8", r0, r1, 8, 30, method="acc-ADMM", restart=7)
+    trajectory("traj_accadmm_theta3_16x12x8", r0, r1, 8, 20, method="acc-ADMM", theta=3.0, restart=6)
+    r0, r1 = get_example_2d("example1", 16, 16)
+    r0, r1, _ = ensure_barrier_validity(r0, r1, b)
+    trajectory("traj_waccadmm_16x16x8", r0, r1, 8, 25, weight=w, method="acc-ADMM")
     print("golden vectors written to", HERE)
