@@ -96,7 +96,8 @@ def test_bfd1d_and_conj1d(nt, nx):
 
 @pytest.mark.parametrize("shape", [(8, 4, 2), (64, 32, 16), (256, 8, 4), (16, 256, 8), (4, 16, 128), (1024, 2, 2),
                                    (5, 6, 7), (33, 17, 9), (129, 3, 2), (16, 1, 8), (129, 1, 33),
-                                   (129, 65, 33), (65, 129, 40), (257, 257, 5)])
+                                   (129, 65, 33), (65, 129, 40), (257, 257, 5),
+                                   (96, 100, 48), (50, 70, 66), (192, 3, 80)])   # even lengths that are no powers of two
 def test_dctn_matches_scipy(shape):
     a = np.asfortranarray(rng.standard_normal(shape))
     tol = 2e-13 * np.sqrt(np.prod(shape))
