@@ -120,3 +120,21 @@ def test_mex_1d_argument_errors():
         D.mexBFdConj1d(q, z, 4)
     with pytest.raises(ValueError, match="invalidInput"):
         D.mexBFd1d(np.zeros((5, 6), order="F"), q, 4, 4)
+
+
+@pytest.mark.parametrize("method", ["inPALM", "PALM", "acc-ADMM"])
+def test_time_limit_stops_at_the_next_kkt_check(method):
+    """opts.time_limit (solver_socp_inPALM.m:26-30,221,287-290): once exceeded, the current iteration ends with a KKT
+    check and the loop breaks -- here in the very first iteration."""
+    from oracle import driver as OD
+    from oracle.examples import get_example_2d
+    rho0, rho1 = get_example_2d("example1", 16, 16)
+    var, model = D.initialize(rho0, rho1, 8)
+    D.InitialScaling(var, model, True, None, dim=2)
+    o = OD.default_opts(dict(tol=0.0, maxit=50, time_limit=1e-9), method)
+    ctx = D.InPALMContext(var, o, model, method=method)
+    assert ctx.run(-1) == 1
+    hist, sigma = ctx.finish()
+    ctx.close()
+    assert hist["len"] == 1 and hist["iter"][0] == 1 and ctx.result.stopped == 1
+    assert np.all(np.isfinite(var.phi)) and np.all(np.isfinite(hist["kkt"]))
