@@ -9,8 +9,7 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows
 import numpy as np
 
 from . import mexops
-from .driver import InitialScaling, default_opts, recoverOrgVar
-from .inpalm import InPALMState
+from .driver import InitialScaling, default_opts, make_state, recoverOrgVar
 from .model import initialize
 
 
@@ -212,7 +211,7 @@ def solve_multilevel(rho0, rho1, nt, levelN, opts, method="inPALM", weight=None,
     for lv in range(levelN):
         InitialScaling(var, model, o["scaling"], last, dim=dim, weighted=weighted)
         o2 = dict(o, tol=tols[lv])
-        st = InPALMState(var, o2, model, weighted=weighted)
+        st = make_state(var, o2, model, method, weighted=weighted)      # solver_dotsocp2d.m:205-226
         st.run()
         runHist, sigma = st.finish()
         recoverOrgVar(var)

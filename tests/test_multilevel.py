@@ -159,3 +159,18 @@ def test_device_outputs_equal_host_recovery(case):
     for k in names:
         assert dev[k].shape == host[k].shape, k
         np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["acc-ADMM", "PALM"])
+def test_multilevel_loop_variants_against_oracle(method):
+    """The level loop with the other loop files of the reference (solver_dotsocp2d.m:205-226), state resident on the
+    device across levels."""
+    rho0, rho1 = get_example_2d("example1", 33, 33)
+    ovar, omodel, ohists, osigma = OM.solve_multilevel(rho0, rho1, 17, 2, dict(tol=1e-4), method)
+    out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, 17, 2, dict(tol=1e-4), method)
+    assert [int(t["Iters"]) for t in timeML[:2]] == [int(h["iter"][-1]) for h in ohists]
+    rho_o, _, _ = recover_RhoE(ovar, omodel)
+    np.testing.assert_allclose(out["rho"], rho_o, atol=1e-7)
+    assert D.check_massConservation(out["rho"], 1e-2)
+    assert hist["method"] == f"Multilevel-{method} for DOT-SOCP"
