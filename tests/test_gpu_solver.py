@@ -81,6 +81,16 @@ def test_parity_gate_config2(n, nt, K, request):
     _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
 
 
+@pytest.mark.parametrize("ny,nx,nt,K", [(100, 70, 20, 15), (50, 130, 9, 12), (65, 129, 33, 10)])
+def test_trajectory_dot2d_odd_shapes(ny, nx, nt, K):
+    """Lengths that are neither powers of two nor multiples of the tile sizes: partial tiles in y and x, the DCT as a
+    matrix product on the matrix cores (even lengths 100 / 70 / 50 / 130, odd 65 / 129) or the scalar dense kernel
+    (n < 48)."""
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    assert rho0.shape == (ny, nx)
+    _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
+
+
 def test_trajectory_dot2d_rectangular_alg2():
     rho0, rho1 = get_example_2d("example1", 24, 40)     # generator returns (nx, ny) arrays: ny = 24, nx = 40
     _compare_run(rho0, rho1, 12, dict(tol=0.0), 20, method="ALG2")
