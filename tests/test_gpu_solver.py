@@ -81,6 +81,20 @@ def test_parity_gate_config2(n, nt, K, request):
     _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
 
 
+def test_parity_gate_config5_wdot2d(request):
+    """BASELINE configs[4] at its full size: wdot2d 512 x 512 x 128 with the circle-pillar obstacle (weight 1e6 on the
+    barrier edges), K iterations against the oracle (about ten seconds per oracle iteration, hence K = 4 and the
+    production dataflow only); tolerance as in the small weighted cases."""
+    if "unfused" in request.node.name:
+        pytest.skip("production dataflow only at this size")
+    n, nt, K = 512, 128, 4
+    rho0, rho1 = get_example_2d("example1", n, n)
+    barrier = gene_barrier_of_circle_pillar()
+    weight = get_weight_by_barrier(n, n, nt, barrier)
+    rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    _compare_run(rho0, rho1, nt, dict(tol=0.0), K, weight=weight, tol=1e-8)
+
+
 @pytest.mark.parametrize("ny,nx,nt,K", [(100, 70, 20, 15), (50, 130, 9, 12), (65, 129, 33, 10)])
 def test_trajectory_dot2d_odd_shapes(ny, nx, nt, K):
     """Lengths that are neither powers of two nor multiples of the tile sizes: partial tiles in y and x, the DCT as a
