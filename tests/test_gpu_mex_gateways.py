@@ -1,0 +1,198 @@
+"""The MEX gateways of dot-socp_amd/mex/ (boundary B1 / B2 as MATLAB would see it) EXECUTED on a box without
+MATLAB: they are compiled against a small stand-in for libmx / libmex written for this purpose
+(tests/fake_mx/fake_mx.c, test infrastructure: real double matrices, 1 x 1 structs, strings,
+mexErrMsgIdAndTxt as a non-local exit) and their mexFunction is called through ctypes with the arguments the
+reference's MATLAB code passes (solver_socp_inPALM.m:133,187,199,205; solver_dotsocp2d.m:208).  Checked: in-place
+semantics of the first argument, scalar truncation, the error identifiers of the 1-D binaries, and the solver
+gateway's output struct against the Python binding of the same C ABI."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from oracle import driver as OD, mexops as O
+from oracle.examples import get_example_2d
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MEX = os.path.join(ROOT, "dot-socp_amd", "mex")
+OUT = os.path.join(ROOT, "tests", "fake_mx", "_build")
+vp = ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def mx():
+    os.makedirs(OUT, exist_ok=True)
+    fake = os.path.join(OUT, "libfake_mx.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-o", fake,
+                           os.path.join(ROOT, "tests", "fake_mx", "fake_mx.c")])
+    L = ctypes.CDLL(fake, mode=ctypes.RTLD_GLOBAL)
+    for name, res, args in [("fmx_wrap_double", vp, [ctypes.c_size_t, ctypes.c_size_t, vp]),
+                            ("fmx_string", vp, [ctypes.c_char_p]),
+                            ("fmx_struct", vp, [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]),
+                            ("fmx_free", None, [vp]),
+                            ("fmx_call", ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp)]),
+                            ("fmx_error_id", ctypes.c_char_p, []), ("fmx_error_msg", ctypes.c_char_p, []),
+                            ("mxCreateDoubleScalar", vp, [ctypes.c_double]),
+                            ("mxSetField", None, [vp, ctypes.c_size_t, ctypes.c_char_p, vp]),
+                            ("mxGetField", vp, [vp, ctypes.c_size_t, ctypes.c_char_p]),
+                            ("mxGetPr", ctypes.POINTER(ctypes.c_double), [vp]),
+                            ("mxGetM", ctypes.c_size_t, [vp]), ("mxGetN", ctypes.c_size_t, [vp])]:
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    gates = {}
+    libdir = os.path.join(ROOT, "dot-socp_amd", "lib")
+    for src in ("mexProjSoc", "mexBFd", "mexBFdConj", "mexBFd1d", "mexBFdConj1d", "dotsocp_inpalm_mex"):
+        so = os.path.join(OUT, src + ".so")
+        subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-I" + os.path.join(MEX, "compile_check"),
+                               "-I" + os.path.join(ROOT, "include"), "-I" + MEX, os.path.join(MEX, src + ".c"), "-o", so,
+                               "-L" + libdir, "-ldotsocp", "-L" + OUT, "-lfake_mx",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath," + OUT])
+        gates[src] = ctypes.CDLL(so).mexFunction
+    D.capi.lib()                      # same libdotsocp instance as the Python binding
+    return L, gates
+
+
+class Call:
+    """Builds prhs from numpy arrays (aliased, so in-place writes are visible), scalars and dicts, runs the gateway."""
+
+    def __init__(self, L):
+        self.L, self.keep, self.made = L, [], []
+
+    def arg(self, v):
+        L = self.L
+        if isinstance(v, np.ndarray):
+            a = v if v.flags.f_contiguous else np.asfortranarray(v)
+            assert a is v, "pass Fortran-ordered arrays so that in-place results are visible"
+            m, n = (a.shape[0], a.shape[1]) if a.ndim == 2 else (a.size, 1)
+            h = L.fmx_wrap_double(m, n, a.ctypes.data)
+        elif isinstance(v, str):
+            h = L.fmx_string(v.encode())
+        elif isinstance(v, dict):
+            names = (ctypes.c_char_p * len(v))(*[k.encode() for k in v])
+            h = L.fmx_struct(len(v), names)
+            for k, x in v.items():
+                L.mxSetField(h, 0, k.encode(), self.arg(x))      # the struct owns its fields
+            self.made.append(h)
+            return h
+        else:
+            buf = np.array([float(v)])
+            self.keep.append(buf)
+            h = L.fmx_wrap_double(1, 1, buf.ctypes.data)
+        self.keep.append(v)
+        return h
+
+    def run(self, fn, args, nlhs=0):
+        hs = []
+        for v in args:
+            h = self.arg(v)
+            hs.append(h)
+            if not isinstance(v, dict):
+                self.made.append(h)
+        prhs = (vp * max(len(hs), 1))(*hs)
+        plhs = (vp * max(nlhs, 1))()
+        rc = self.L.fmx_call(ctypes.cast(fn, vp), nlhs, plhs, len(hs), prhs)
+        err = (self.L.fmx_error_id().decode(), self.L.fmx_error_msg().decode()) if rc else None
+        return err, [plhs[i] for i in range(nlhs)]
+
+
+def _field(L, s, name):
+    h = L.mxGetField(s, 0, name.encode())
+    assert h, name
+    m, n = L.mxGetM(h), L.mxGetN(h)
+    return np.ctypeslib.as_array(L.mxGetPr(h), shape=(m * n,)).reshape((m, n), order="F").copy()
+
+
+def test_operator_gateways_in_place(mx):
+    L, g = mx
+    rng = np.random.default_rng(5)
+    nt, nx, ny = 4, 6, 5
+    Nz = ny * nx * (nt - 1)
+    Nq = Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt
+    x = np.asfortranarray(rng.standard_normal((Nz, 10)))
+    out = np.full((Nz, 10), 7.0, order="F")
+    ref = np.empty_like(out, order="F")
+    O.mexProjSoc(ref, x)
+    err, _ = Call(L).run(g["mexProjSoc"], [out, x])
+    assert err is None and np.array_equal(out, ref)
+    q = rng.standard_normal(Nq)
+    z, zr = np.zeros((Nz, 10), order="F"), np.zeros((Nz, 10), order="F")
+    O.mexBFd(zr, q, nt, nx, ny, 0.7, 1.3)
+    err, _ = Call(L).run(g["mexBFd"], [z, q, nt + 0.9, nx, ny, 0.7, 1.3])       # doubles are truncated (cvttsd2si)
+    assert err is None and np.array_equal(z, zr)
+    qa, qr = np.zeros(Nq), np.zeros(Nq)
+    O.mexBFdConj(qr, x, nt, nx, ny, 0.7)
+    err, _ = Call(L).run(g["mexBFdConj"], [qa, x, nt, nx, ny, 0.7])
+    assert err is None and np.array_equal(qa, qr)
+    z5, z5r = np.zeros((Nz, 10), order="F"), np.zeros((Nz, 10), order="F")       # defaults scale = dF = 1
+    O.mexBFd(z5r, q, nt, nx, ny, 1.0, 1.0)
+    err, _ = Call(L).run(g["mexBFd"], [z5, q, nt, nx, ny])
+    assert err is None and np.array_equal(z5, z5r)
+
+
+def test_1d_gateways_and_their_error_identifiers(mx):
+    L, g = mx
+    rng = np.random.default_rng(6)
+    nt, nx = 5, 9
+    Nz, Nq = nx * (nt - 1), nx * (nt - 1) + (nx - 1) * nt
+    q = rng.standard_normal(Nq)
+    z, zr = np.zeros((Nz, 6), order="F"), np.zeros((Nz, 6), order="F")
+    O.mexBFd1d(zr, q, nt, nx, 1.2, 0.6)
+    err, _ = Call(L).run(g["mexBFd1d"], [z, q, nt, nx, 1.2, 0.6])
+    assert err is None and np.array_equal(z, zr)
+    w = np.asfortranarray(rng.standard_normal((Nz, 6)))
+    qa, qr = np.zeros(Nq), np.zeros(Nq)
+    O.mexBFdConj1d(qr, w, nt, nx, 1.2)
+    err, _ = Call(L).run(g["mexBFdConj1d"], [qa, w, nt, nx, 1.2])
+    assert err is None and np.array_equal(qa, qr)
+    # the reference binaries' identifiers
+    err, _ = Call(L).run(g["mexBFd1d"], [z, q, nt])
+    assert err and err[0] == "mexBFd:invalidNumInputs"
+    err, _ = Call(L).run(g["mexBFd1d"], [z, q, nt, nx], nlhs=1)
+    assert err and err[0] == "mexBFd:invalidNumOutputs"
+    err, _ = Call(L).run(g["mexBFd1d"], [z, q, nt, nx, np.ones(2)])
+    assert err and err[0] == "mexBFd:invalidInput"
+    err, _ = Call(L).run(g["mexBFd1d"], [np.zeros((Nz + 1, 6), order="F"), q, nt, nx])
+    assert err and err[0] == "mexBFd:invalidInput"
+
+
+@pytest.mark.parametrize("method", ["inPALM", "accADMM", "PALM"])
+def test_solver_gateway_matches_the_python_binding(mx, method):
+    """dotsocp_inpalm_mex(S, opts) as solver_socp_inPALM.m / solver_socp_accADMM.m / solver_socp_PALM.m call it."""
+    L, g = mx
+    rho0, rho1 = get_example_2d("example1", 24, 16)
+    nt, K = 8, 14
+    pym = {"inPALM": "inPALM", "accADMM": "acc-ADMM", "PALM": "PALM"}[method]
+    o = OD.default_opts(dict(tol=0.0, maxit=K), pym)
+    var, model = D.initialize(rho0, rho1, nt)
+    D.InitialScaling(var, model, True, None, dim=2)
+    S = dict(phi=var.phi.copy(), q=var.q.copy(), alpha=var.alpha.copy(), z=var.z.copy(order="F"), beta=var.beta.copy(order="F"),
+             c=model.c.copy(), nx=model.nx, ny=model.ny, nt=model.nt, D=var.D, E=var.E, cScale=var.cScale,
+             dScale=var.dScale, normc=model.normc, normd=model.normd)
+    opts = dict(sigma=o["sigma"], maxit=o["maxit"], tol=o["tol"], ifCheckStepByStep=0.0, scaling=1.0, method=method)
+    if method != "accADMM":
+        opts["tau"] = o["tau"]
+    call = Call(L)
+    err, outs = call.run(g["dotsocp_inpalm_mex"], [S, opts], nlhs=1)
+    assert err is None, err
+    out = outs[0]
+    solve = {"inPALM": D.solver_socp_inPALM, "accADMM": D.solver_socp_accADMM, "PALM": D.solver_socp_PALM}[method]
+    hist, sigma = solve(var, o, model)
+    for f in ("phi", "q", "alpha"):
+        np.testing.assert_array_equal(_field(L, out, f).ravel(order="F"), getattr(var, f))
+    for f in ("z", "beta"):
+        np.testing.assert_array_equal(_field(L, out, f), getattr(var, f))
+    assert float(_field(L, out, "sigma")[0, 0]) == sigma
+    np.testing.assert_array_equal(_field(L, out, "kkt"), hist["kkt"])
+    np.testing.assert_array_equal(_field(L, out, "iter").ravel(), hist["iter"])
+    assert float(_field(L, out, "cScale")[0, 0]) == var.cScale and float(_field(L, out, "dScale")[0, 0]) == var.dScale
+    assert _field(L, out, "times").shape == (1, 7)
+    L.fmx_free(out)
+    # a missing required field is a MATLAB error, not a crash
+    bad = dict(opts)
+    del bad["sigma"]
+    err, _ = Call(L).run(g["dotsocp_inpalm_mex"], [S, bad], nlhs=1)
+    assert err and err[0] == "dotsocp:inPALM" and "sigma" in err[1]
