@@ -61,3 +61,39 @@ def test_no_cpu_fallback():
     dotsocp_amd.InitialScaling(var, model, True)
     with pytest.raises(capi.DotsocpError):
         dotsocp_amd.solver_socp_inPALM(var, dict(tau=1.9, sigma=1.0, tol=1e-3, maxit=3), model)
+
+
+def test_mex_gateways_build_and_reject_bad_calls_without_a_gpu():
+    """The MEX gateways link against libdotsocp and a stand-in libmx (tests/fake_mx), export mexFunction, and their
+    argument checks fire before any device work (so this runs on the CPU-only box; the compute paths are in
+    tests/test_gpu_mex_gateways.py)."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mexdir = os.path.join(root, "dot-socp_amd", "mex")
+    out = os.path.join(root, "tests", "fake_mx", "_build")
+    os.makedirs(out, exist_ok=True)
+    fake = os.path.join(out, "libfake_mx.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-o", fake,
+                           os.path.join(root, "tests", "fake_mx", "fake_mx.c")])
+    L = ctypes.CDLL(fake, mode=ctypes.RTLD_GLOBAL)
+    vp = ctypes.c_void_p
+    L.fmx_wrap_double.restype, L.fmx_wrap_double.argtypes = vp, [ctypes.c_size_t, ctypes.c_size_t, vp]
+    L.fmx_call.restype = ctypes.c_int
+    L.fmx_call.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp)]
+    L.fmx_error_id.restype = ctypes.c_char_p
+    libdir = os.path.join(root, "dot-socp_amd", "lib")
+    for src in ("mexProjSoc", "mexBFd", "mexBFdConj", "mexBFd1d", "mexBFdConj1d", "dotsocp_inpalm_mex"):
+        so = os.path.join(out, src + ".so")
+        subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-I" + os.path.join(mexdir, "compile_check"),
+                               "-I" + os.path.join(root, "include"), "-I" + mexdir, os.path.join(mexdir, src + ".c"),
+                               "-o", so, "-L" + libdir, "-ldotsocp", "-L" + out, "-lfake_mx",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath," + out])
+        fn = ctypes.CDLL(so).mexFunction
+        assert fn
+        if src == "mexBFd1d":
+            z, q, s = np.zeros(12), np.zeros(20), np.array([4.0])
+            hs = [L.fmx_wrap_double(a.size, 1, a.ctypes.data) for a in (z, q, s)]
+            prhs, plhs = (vp * 3)(*hs), (vp * 1)()
+            assert L.fmx_call(ctypes.cast(fn, vp), 0, plhs, 3, prhs) == 1
+            assert L.fmx_error_id() == b"mexBFd:invalidNumInputs"
