@@ -159,19 +159,31 @@ def test_1d_gateways_and_their_error_identifiers(mx):
     assert err and err[0] == "mexBFd:invalidInput"
 
 
-@pytest.mark.parametrize("method", ["inPALM", "accADMM", "PALM"])
-def test_solver_gateway_matches_the_python_binding(mx, method):
-    """dotsocp_inpalm_mex(S, opts) as solver_socp_inPALM.m / solver_socp_accADMM.m / solver_socp_PALM.m call it."""
+@pytest.mark.parametrize("method,weighted", [("inPALM", False), ("accADMM", False), ("PALM", False), ("inPALM", True),
+                                             ("accADMM", True)])
+def test_solver_gateway_matches_the_python_binding(mx, method, weighted):
+    """dotsocp_inpalm_mex(S, opts) as solver_socp_inPALM.m / solver_wsocp_inPALM.m / solver_socp_accADMM.m /
+    solver_wsocp_accADMM.m / solver_socp_PALM.m call it (dotsocp_run_inpalm.m)."""
+    from oracle.examples import ensure_barrier_validity, gene_barrier_of_circle_pillar, get_weight_by_barrier
     L, g = mx
     rho0, rho1 = get_example_2d("example1", 24, 16)
     nt, K = 8, 14
     pym = {"inPALM": "inPALM", "accADMM": "acc-ADMM", "PALM": "PALM"}[method]
-    o = OD.default_opts(dict(tol=0.0, maxit=K), pym)
+    o = OD.default_opts(dict(tol=0.0, maxit=K), pym, weighted)
+    weight = None
+    if weighted:
+        barrier = gene_barrier_of_circle_pillar()
+        weight = get_weight_by_barrier(16, 24, nt, barrier)
+        rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
     var, model = D.initialize(rho0, rho1, nt)
-    D.InitialScaling(var, model, True, None, dim=2)
+    if weighted:
+        model.weight = weight
+    D.InitialScaling(var, model, True, None, dim=2, weighted=weighted)
     S = dict(phi=var.phi.copy(), q=var.q.copy(), alpha=var.alpha.copy(), z=var.z.copy(order="F"), beta=var.beta.copy(order="F"),
              c=model.c.copy(), nx=model.nx, ny=model.ny, nt=model.nt, D=var.D, E=var.E, cScale=var.cScale,
              dScale=var.dScale, normc=model.normc, normd=model.normd)
+    if weighted:
+        S["weight"] = weight.copy()
     opts = dict(sigma=o["sigma"], maxit=o["maxit"], tol=o["tol"], ifCheckStepByStep=0.0, scaling=1.0, method=method)
     if method != "accADMM":
         opts["tau"] = o["tau"]
@@ -179,7 +191,9 @@ def test_solver_gateway_matches_the_python_binding(mx, method):
     err, outs = call.run(g["dotsocp_inpalm_mex"], [S, opts], nlhs=1)
     assert err is None, err
     out = outs[0]
-    solve = {"inPALM": D.solver_socp_inPALM, "accADMM": D.solver_socp_accADMM, "PALM": D.solver_socp_PALM}[method]
+    solve = {("inPALM", False): D.solver_socp_inPALM, ("accADMM", False): D.solver_socp_accADMM,
+             ("PALM", False): D.solver_socp_PALM, ("inPALM", True): D.solver_wsocp_inPALM,
+             ("accADMM", True): D.solver_wsocp_accADMM}[(method, weighted)]
     hist, sigma = solve(var, o, model)
     for f in ("phi", "q", "alpha"):
         np.testing.assert_array_equal(_field(L, out, f).ravel(order="F"), getattr(var, f))
