@@ -56,6 +56,13 @@ def mx():
     return L, gates
 
 
+class Mx:
+    """An mxArray returned by a gateway, passed on to another call as it is (e.g. a level handle)."""
+
+    def __init__(self, h):
+        self.h = h
+
+
 class Call:
     """Builds prhs from numpy arrays (aliased, so in-place writes are visible), scalars and dicts, runs the gateway."""
 
@@ -64,6 +71,8 @@ class Call:
 
     def arg(self, v):
         L = self.L
+        if isinstance(v, Mx):
+            return v.h
         if isinstance(v, np.ndarray):
             a = v if v.flags.f_contiguous else np.asfortranarray(v)
             assert a is v, "pass Fortran-ordered arrays so that in-place results are visible"
@@ -90,7 +99,7 @@ class Call:
         for v in args:
             h = self.arg(v)
             hs.append(h)
-            if not isinstance(v, dict):
+            if not isinstance(v, (dict, Mx)):
                 self.made.append(h)
         prhs = (vp * max(len(hs), 1))(*hs)
         plhs = (vp * max(nlhs, 1))()
@@ -210,3 +219,73 @@ def test_solver_gateway_matches_the_python_binding(mx, method, weighted):
     del bad["sigma"]
     err, _ = Call(L).run(g["dotsocp_inpalm_mex"], [S, bad], nlhs=1)
     assert err and err[0] == "dotsocp:inPALM" and "sigma" in err[1]
+
+
+def test_level_gateway_runs_the_multilevel_driver_on_the_device(mx):
+    """dotsocp_level_mex: the call sequence a MATLAB solver_dotsocp2d.m would issue for levelN = 2 (create, solve,
+    create-from-coarse, destroy, solve, outputs), with the host-side level logic of solver_dotsocp2d.m:154-250 done
+    here in Python; must reproduce D.solver_dotsocp2d (same library underneath) exactly."""
+    from dotsocp_amd import multilevel as ML
+    L, g = mx
+    so = os.path.join(OUT, "dotsocp_level_mex.so")
+    libdir = os.path.join(ROOT, "dot-socp_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-I" + os.path.join(MEX, "compile_check"),
+                           "-I" + os.path.join(ROOT, "include"), "-I" + MEX, os.path.join(MEX, "dotsocp_level_mex.c"),
+                           "-o", so, "-L" + libdir, "-ldotsocp", "-L" + OUT, "-lfake_mx",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath," + OUT])
+    gate = ctypes.CDLL(so).mexFunction
+
+    def call(*args, nlhs=1):
+        err, outs = Call(L).run(gate, list(args), nlhs=nlhs)
+        assert err is None, err
+        return outs[0] if nlhs else None
+
+    n, nt, tol = 33, 17, 1e-4
+    rho0, rho1 = get_example_2d("example1", n, n)
+    ref_out, ref_time, ref_histML, ref_hist = D.solver_dotsocp2d(rho0, rho1, nt, 2, dict(tol=tol), "inPALM")
+    # ---- the driver's host side (solver_dotsocp2d.m:154-250) ----
+    o = OD.default_opts(dict(tol=tol), "inPALM")
+    r0c, r1c = ML.downSample_phi(rho0), ML.downSample_phi(rho1)
+    r0c, r1c = r0c / (r0c.sum() / r0c.size), r1c / (r1c.sum() / r1c.size)
+    ntc = (nt - 1) // 2 + 1
+    tolc = max(tol * 2 ** (-0.5), 1e-4)
+
+    def level_struct(var, model):
+        S = dict(c=model.c.copy(), nx=model.nx, ny=model.ny, nt=model.nt, D=var.D, E=var.E, cScale=var.cScale,
+                 dScale=var.dScale, normc=model.normc, normd=model.normd)
+        if var.phi is not None:
+            S["phi"] = var.phi.copy()
+        return S
+
+    def mopts(o, tol_):
+        return dict(tau=o["tau"], sigma=o["sigma"], maxit=o["maxit"], tol=tol_, ifCheckStepByStep=0.0, scaling=1.0,
+                    time_limit=o["time_limit"])
+
+    var, model = D.initialize(r0c, r1c, ntc, lazy_zeros=True)
+    D.InitialScaling(var, model, True, None, dim=2)
+    h1 = Mx(call("create", level_struct(var, model), mopts(o, tolc)))
+    out1 = call("solve", h1)
+    kkt1, sigma1 = _field(L, out1, "kkt"), float(_field(L, out1, "sigma")[0, 0])
+    iters1 = int(_field(L, out1, "iter")[-1, 0])
+    o["sigma"] = 10 ** (np.log10(o["sigma"] * sigma1) / 2)
+    E2 = var.E2
+    var, model = D.initialize(rho0, rho1, nt, lazy_zeros=True)
+    var.phi, var.E2 = None, E2
+    model.n_global = model.c.size
+    D.InitialScaling(var, model, True, kkt1[-1], dim=2)
+    h2 = Mx(call("create", level_struct(var, model), mopts(o, tol), h1))
+    call("destroy", h1, nlhs=0)
+    out2 = call("solve", h2)
+    iters2 = int(_field(L, out2, "iter")[-1, 0])
+    outs = call("outputs", h2, np.asfortranarray(rho0), np.asfortranarray(rho1))
+    st = call("fields", h2)
+    call("destroy", h2, nlhs=0)
+    assert [iters1, iters2] == [int(t["Iters"]) for t in ref_time[:2]]
+    np.testing.assert_array_equal(_field(L, out2, "kkt"), ref_hist["kkt"])
+    for k in ("rho", "Ex", "Ey", "q0", "bx", "by"):
+        got = _field(L, outs, k).reshape(ref_out[k].shape, order="F")
+        np.testing.assert_array_equal(got, ref_out[k], err_msg=k)
+    assert _field(L, st, "beta").shape == (n * n * (nt - 1), 10) and np.all(np.isfinite(_field(L, st, "phi")))
+    # a stale handle is an error, not a crash
+    err, _ = Call(L).run(gate, ["solve", h2], nlhs=1)
+    assert err and err[0] == "dotsocp:level"
