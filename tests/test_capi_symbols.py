@@ -83,7 +83,8 @@ def test_mex_gateways_build_and_reject_bad_calls_without_a_gpu():
     L.fmx_call.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp)]
     L.fmx_error_id.restype = ctypes.c_char_p
     libdir = os.path.join(root, "dot-socp_amd", "lib")
-    for src in ("mexProjSoc", "mexBFd", "mexBFdConj", "mexBFd1d", "mexBFdConj1d", "dotsocp_inpalm_mex"):
+    for src in ("mexProjSoc", "mexBFd", "mexBFdConj", "mexBFd1d", "mexBFdConj1d", "dotsocp_inpalm_mex",
+                "dotsocp_level_mex"):
         so = os.path.join(out, src + ".so")
         subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-I" + os.path.join(mexdir, "compile_check"),
                                "-I" + os.path.join(root, "include"), "-I" + mexdir, os.path.join(mexdir, src + ".c"),
