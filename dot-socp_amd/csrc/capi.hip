@@ -78,9 +78,9 @@ int dotsocp_bfd_conj_dev(double *d_q, const double *d_z, dotsocp_i64 nt, dotsocp
 // ------------------------------------------------------------------ B2, host pointers
 int dotsocp_proj_soc(double *out, const double *in, dotsocp_i64 M, dotsocp_i64 K) {
     DS_ARG(M >= 0 && K >= 2, "mexProjSoc needs an M x K matrix with K >= 2");
+    if (M == 0) return 0;                      // empty matrix (mxGetPr may be NULL): nothing to do, like the reference
     DS_ARG(out && in, "NULL pointer");
     DS_CHECK(require_device());
-    if (M == 0) return 0;
     DevBuf a, b;
     DS_CHECK(a.alloc(M * K));
     DS_CHECK(b.alloc(M * K));

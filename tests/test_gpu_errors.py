@@ -138,3 +138,18 @@ def test_time_limit_stops_at_the_next_kkt_check(method):
     ctx.close()
     assert hist["len"] == 1 and hist["iter"][0] == 1 and ctx.result.stopped == 1
     assert np.all(np.isfinite(var.phi)) and np.all(np.isfinite(hist["kkt"]))
+
+
+def test_empty_and_degenerate_operator_inputs():
+    """Zero rows are a no-op; grids too small for a cell are rejected with a message (the reference binaries would
+    index out of bounds)."""
+    L = capi.lib()
+    x = np.zeros((0, 10), order="F")
+    capi.check(L.dotsocp_proj_soc(None if x.size == 0 else capi.fptr(x), None, 0, 10))
+    z, q = np.zeros((1, 10), order="F"), np.zeros(1)
+    assert _code(L.dotsocp_bfd(capi.fptr(z), capi.fptr(q), 1, 1, 1, 1.0, 1.0)) == -1          # nt = 1: no cell
+    one = np.array([[3.0, 0.0, 4.0, 0, 0, 0, 0, 0, 0, 0]], order="F")                           # a single row
+    out = np.empty_like(one, order="F")
+    D.mexProjSoc(out, one)
+    c = (3.0 / 4.0 + 1.0) / 2.0
+    np.testing.assert_allclose(out[0, :3], [c * 4.0, 0.0, c * 4.0], rtol=1e-15)
