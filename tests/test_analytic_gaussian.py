@@ -44,3 +44,31 @@ def test_gpu_reaches_the_analytic_geodesic():
     out, timeML, histML, hist = D.solver_dotsocp1d(rho0, rho1, 129, 3, dict(tol=1e-5, maxit=20000), "inPALM")
     worst, cost = _check(out["rho"], out["Ex"], tol_l1=0.012, tol_cost=0.004)      # finer grid: closer
     assert D.check_massConservation(out["rho"], 1e-2)
+
+
+@pytest.mark.gpu
+def test_gpu_translation_of_a_gaussian_in_2d():
+    """Two equal isotropic Gaussians well inside the unit square: the optimal map is the translation, the density at
+    time t the same Gaussian centred on the straight line between the centres, the cost |shift|^2."""
+    import dotsocp_amd as D
+    n, nt, s = 129, 33, 0.06
+    x = np.linspace(0, 1, n)
+    Y, X = np.meshgrid(x, x, indexing="ij")                 # arrays are (ny, nx)
+
+    def bump(cy, cx):
+        g = np.exp(-0.5 * (((Y - cy) / s) ** 2 + ((X - cx) / s) ** 2))
+        return g / g.mean()
+
+    (cy0, cx0), (cy1, cx1) = (0.3, 0.35), (0.7, 0.6)
+    out, timeML, histML, hist = D.solver_dotsocp2d(bump(cy0, cx0), bump(cy1, cx1), nt, 3, dict(tol=1e-5, maxit=20000),
+                                                   "inPALM")
+    assert D.check_massConservation(out["rho"], 1e-2)
+    worst = 0.0
+    for k, t in enumerate(np.linspace(0, 1, nt)):
+        g = bump((1 - t) * cy0 + t * cy1, (1 - t) * cx0 + t * cx1)
+        worst = max(worst, float(np.mean(np.abs(out["rho"][:, :, k] - g))))
+    assert worst <= 0.05, worst
+    ok = out["rho"] > 1e-8
+    cost = float(np.mean(np.where(ok, (out["Ex"] ** 2 + out["Ey"] ** 2) / np.where(ok, out["rho"], 1.0), 0.0)))
+    w2 = (cy1 - cy0) ** 2 + (cx1 - cx0) ** 2
+    assert abs(cost - w2) <= 0.02 * w2, (cost, w2)
