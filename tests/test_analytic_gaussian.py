@@ -47,7 +47,8 @@ def test_gpu_reaches_the_analytic_geodesic():
 
 
 @pytest.mark.gpu
-def test_gpu_translation_of_a_gaussian_in_2d():
+@pytest.mark.parametrize("method", ["inPALM", "ALG2", "PALM", "acc-ADMM"])
+def test_gpu_translation_of_a_gaussian_in_2d(method):
     """Two equal isotropic Gaussians well inside the unit square: the optimal map is the translation, the density at
     time t the same Gaussian centred on the straight line between the centres, the cost |shift|^2."""
     import dotsocp_amd as D
@@ -61,7 +62,7 @@ def test_gpu_translation_of_a_gaussian_in_2d():
 
     (cy0, cx0), (cy1, cx1) = (0.3, 0.35), (0.7, 0.6)
     out, timeML, histML, hist = D.solver_dotsocp2d(bump(cy0, cx0), bump(cy1, cx1), nt, 3, dict(tol=1e-5, maxit=20000),
-                                                   "inPALM")
+                                                   method)
     assert D.check_massConservation(out["rho"], 1e-2)
     worst = 0.0
     for k, t in enumerate(np.linspace(0, 1, nt)):
