@@ -6,8 +6,9 @@ Import as `import dotsocp_amd` (alias module at the repository root; the directo
 no CPU fallback; see include/dotsocp.h for the C ABI and INTEGRATION.md for the MATLAB binding.
 """
 from . import capi  # noqa: F401
-from .examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, get_example_1d,  # noqa: F401
-                       get_example_2d, get_weight_by_barrier)
+from .examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, gene_barrier_of_love_heart,  # noqa: F401
+                       gene_weight_circle, gene_weight_circleInv, get_example_1d, get_example_2d,
+                       get_weight_by_barrier)
 from .mexops import (mexBFd, mexBFd1d, mexBFdConj, mexBFdConj1d, mexProjSoc, mirt_dctn, mirt_idctn,  # noqa: F401
                      oper_poisson, oper_poisson3dim)
 from .model import (InitialScaling, ModelHandle, VarHandle, check_massConservation, initialize,  # noqa: F401
