@@ -195,7 +195,7 @@ def main():
     hist, sigma = ctx.finish(download=False)
     times = {k: ctx.kernel_time(k) for k in ("rhs", "poisson", "cone_fused_a", "cone_fused_b", "cone_proj",
                                              "qstep", "beta", "materialise", "kkt", "comm", "interp", "acc_cone",
-                                             "acc_gather", "qstep_first")}
+                                             "acc_gather", "qstep_first", "transpose")}
     ctx.close()
 
     # per-launch sizes of THIS rank's slab (the whole grid at N = 1)

@@ -321,7 +321,7 @@ int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dots
     DS_ARG(name != nullptr, "name is NULL");
     static const char *names[PH_COUNT] = {"rhs", "poisson", "cone_proj", "qstep", "beta", "kkt",
                                           "cone_fused_a", "cone_fused_b", "materialise", "comm",
-                                          "interp", "acc_cone", "acc_gather", "qstep_first"};
+                                          "interp", "acc_cone", "acc_gather", "qstep_first", "transpose"};
     for (int i = 0; i < PH_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) {
             const i64 n = ctx->s.phase_launches[i];

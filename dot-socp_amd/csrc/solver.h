@@ -64,7 +64,7 @@ struct Slab {
 bool if_adjust_sigma(double iter, double last_iter);   // IfAdjustSigma (solver_socp_inPALM.m:361-379)
 
 enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_FUSED_A, PH_FUSED_B, PH_MATERIALISE,
-             PH_COMM, PH_INTERP, PH_ACC_CONE, PH_ACC_GATHER, PH_QSTEP0, PH_COUNT };
+             PH_COMM, PH_INTERP, PH_ACC_CONE, PH_ACC_GATHER, PH_QSTEP0, PH_TRANSPOSE, PH_COUNT };
 
 struct Solver {
     dotsocp_problem prob{};

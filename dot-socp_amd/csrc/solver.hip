@@ -617,7 +617,11 @@ int Solver::poisson_all() {
         DS_CHECK(launch_dct_axis(py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, stream));
         DS_CHECK(launch_dct_axis(px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, stream));
     }
-    if (multi()) DS_CHECK(transpose(true));
+    if (multi()) {       // timed on its own (inside "poisson") so that the scaling runs show what the all-to-alls cost
+        prof_begin(PH_TRANSPOSE);
+        DS_CHECK(transpose(true));
+        prof_end(PH_TRANSPOSE);
+    }
     for (auto &s : slabs) {
         double *p = multi() ? s.pencil : s.w0;
         double *p2 = multi() ? s.pencil2 : s.w1;
@@ -629,7 +633,11 @@ int Solver::poisson_all() {
             DS_CHECK(launch_dct_axis(pt, p2, p, s.nl, 1, nt, 2, 1, stream));
         }
     }
-    if (multi()) DS_CHECK(transpose(false));
+    if (multi()) {
+        prof_begin(PH_TRANSPOSE);
+        DS_CHECK(transpose(false));
+        prof_end(PH_TRANSPOSE);
+    }
     for (auto &s : slabs) {
         const Grid &g = s.g;
         DS_CHECK(launch_dct_axis(px, s.w0, s.w1, g.ny, g.nx, g.ntl, 1, 1, stream));
