@@ -153,6 +153,16 @@ struct PencilCuts {
 };
 int launch_pencil_pack(bool pack, const PencilCuts &pc, i64 plane, i64 ntl, double *slab, double *stage, hipStream_t st);
 
+// ---------------- tri.hip: time-slab Poisson solve by partitioned tridiagonal systems (no transposes) ----------------
+#define TRI_EXTRA 256     // room for the whole (0, 0) line of a slab in a message: slabs of at most 256 time nodes
+int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
+                     const double *r, double *send, hipStream_t st);
+int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
+                       int rank, i64 l0, i64 nl, const i64 *slab_n, const double *recv, double *back, double *zero_work,
+                       hipStream_t st);
+int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
+                     const double *back, double *x, double *qinv, hipStream_t st);
+
 // ---------------- kkt.hip ----------------
 struct KktWork {
     double *partials;   // [maxBlocks][S_COUNT]

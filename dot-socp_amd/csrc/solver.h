@@ -54,6 +54,8 @@ struct Slab {
     // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
     double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
     double *alpha2 = nullptr;   // ping-pong partner of alpha (q-step that also forms the next rhs)
+    // partitioned tridiagonal t-solve (tri.hip): messages to / from the owners of the modes, zero-mode work line
+    double *tri_send = nullptr, *tri_recv = nullptr, *tri_bsend = nullptr, *tri_brecv = nullptr, *tri_zero = nullptr;
     FusedGeom fg{};
     // acc-ADMM loop (solver_acc.hip): x^+ of the iteration (q^+ lives in q_old, beta^+ in beta2) and the
     // Halpern anchors / previous extrapolation points
@@ -160,6 +162,11 @@ struct Solver {
     int exchange_u0_tail();
     int group_begin();
     int group_end();
+    bool tri_tsolve = true;  // time-slab Poisson solve by partitioned tridiagonal systems (tri.hip); DOTSOCP_TSOLVE=dct:
+                             // slab <-> pencil transposes around the t-axis DCT instead
+    int tri_alloc();
+    int tri_exchange(bool back);
+    int poisson_t_tridiag();
     bool qrhs = true;        // DOTSOCP_QRHS=0: separate q-step and rhs kernels
     bool rhs_valid = false;  // w0 holds A'(w.*q - alpha) + c of the current iterate (left there by the q-step)
     bool u0_fresh = false;   // u0_prev holds w.*q0 - alpha0 of the CURRENT iterate of the left neighbour

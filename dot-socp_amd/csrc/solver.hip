@@ -37,6 +37,7 @@ void Solver::free_slabs() {
         dfree(s.send_plane); dfree(s.send_plane2); dfree(s.send_bx); dfree(s.send_by);
         dfree(s.kw.partials); dfree(s.kw.sums);
         dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy); dfree(s.alpha2);
+        dfree(s.tri_send); dfree(s.tri_recv); dfree(s.tri_bsend); dfree(s.tri_brecv); dfree(s.tri_zero);
         dfree(s.phi_p); dfree(s.alpha_p); dfree(s.z_p);
         dfree(s.phi_a); dfree(s.q_a); dfree(s.alpha_a); dfree(s.z_a); dfree(s.beta_a);
     }
@@ -117,6 +118,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     overlap = nslabs > 1;                         // pays when there is communication to hide
     if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_QRHS")) qrhs = (atoi(e) != 0);
+    if (const char *e = getenv("DOTSOCP_TSOLVE")) tri_tsolve = (strcmp(e, "dct") != 0);
     DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
     DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
     py = dct_plan_create(ny);
@@ -360,6 +362,97 @@ int Solver::transpose(bool forward) {
         DS_NCCL(api.GroupEnd());
         DS_CHECK(launch_pencil_pack(false, pc, plane, s.g.ntl, s.w0, s.stage, stream));
     }
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// Time-slab Poisson solve without transposes (tri.hip): local eliminations, 2 numbers per mode to the mode's owner,
+// reduced systems there, 2 numbers per mode back, local solves.
+// --------------------------------------------------------------------------------------
+static void tri_layout(i64 plane, i64 nt, int world, PencilCuts &pc, std::vector<i64> &slab_n) {
+    pc.world = world;
+    slab_n.assign(world, 0);
+    for (int j = 0; j < world; ++j) {
+        i64 a, b;
+        pencil_range(plane, world, j, &a, &b);
+        pc.cut[j] = a;
+        pc.cut[j + 1] = b;
+        dotsocp_slab_range_impl(nt, world, j, &a, &b);
+        slab_n[j] = b - a;
+    }
+}
+
+int Solver::tri_alloc() {
+    const i64 plane = ny * nx;
+    for (auto &s : slabs) {
+        if (s.tri_send) continue;
+        DS_CHECK(dzalloc(&s.tri_send, 2 * plane + (i64)TRI_EXTRA * world, stream));
+        DS_CHECK(dzalloc(&s.tri_brecv, 2 * plane + (i64)TRI_EXTRA * world, stream));
+        DS_CHECK(dzalloc(&s.tri_recv, (2 * s.nl + TRI_EXTRA) * world, stream));
+        DS_CHECK(dzalloc(&s.tri_bsend, (2 * s.nl + TRI_EXTRA) * world, stream));
+        DS_CHECK(dzalloc(&s.tri_zero, nt, stream));
+    }
+    return 0;
+}
+
+// back == false: every slab's message for owner j -> owner j (slot of the sending slab); back == true: the way back
+int Solver::tri_exchange(bool back) {
+    const i64 plane = ny * nx;
+    PencilCuts pc{};
+    std::vector<i64> slab_n;
+    tri_layout(plane, nt, world, pc, slab_n);
+    auto off = [&](int j) { return 2 * pc.cut[j] + (i64)TRI_EXTRA * j; };                  // in tri_send / tri_brecv
+    auto cnt = [&](int j) { return 2 * (pc.cut[j + 1] - pc.cut[j]) + (i64)TRI_EXTRA; };  // message for / from owner j
+    if (!remote()) {
+        for (auto &sp : slabs)             // slab p
+            for (auto &sj : slabs) {       // owner j
+                const int p = sp.index, j = sj.index;
+                double *a = sp.tri_send + off(j), *b = sj.tri_recv + (i64)p * cnt(j);
+                if (back) { a = sj.tri_bsend + (i64)p * cnt(j); b = sp.tri_brecv + off(j); }
+                DS_HIP(hipMemcpyAsync(b, a, sizeof(double) * (size_t)cnt(j), hipMemcpyDeviceToDevice, stream));
+            }
+        return 0;
+    }
+    Rccl &api = rccl_api();
+    Slab &s = slabs[0];
+    {
+        double *a = s.tri_send + off(rank), *b = s.tri_recv + (i64)rank * cnt(rank);
+        if (back) { a = s.tri_bsend + (i64)rank * cnt(rank); b = s.tri_brecv + off(rank); }
+        DS_HIP(hipMemcpyAsync(b, a, sizeof(double) * (size_t)cnt(rank), hipMemcpyDeviceToDevice, stream));
+    }
+    DS_NCCL(api.GroupStart());
+    for (int j = 0; j < world; ++j) {
+        if (j == rank) continue;
+        if (!back) {
+            DS_NCCL(api.Send(s.tri_send + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL(api.Recv(s.tri_recv + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
+        } else {
+            DS_NCCL(api.Send(s.tri_bsend + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL(api.Recv(s.tri_brecv + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
+        }
+    }
+    DS_NCCL(api.GroupEnd());
+    return 0;
+}
+
+int Solver::poisson_t_tridiag() {
+    const i64 plane = ny * nx;
+    DS_CHECK(tri_alloc());
+    PencilCuts pc{};
+    std::vector<i64> slab_n;
+    tri_layout(plane, nt, world, pc, slab_n);
+    const double kscale = D * D;
+    for (auto &s : slabs) DS_CHECK(launch_tri_local(s.g, nt, kscale, cy, cx, pc, s.w0, s.tri_send, stream));
+    prof_begin(PH_TRANSPOSE);
+    DS_CHECK(tri_exchange(false));
+    prof_end(PH_TRANSPOSE);
+    for (auto &s : slabs)
+        DS_CHECK(launch_tri_reduced(s.g, nt, kscale, cy, cx, pc, s.index, s.l0, s.nl, slab_n.data(), s.tri_recv, s.tri_bsend,
+                                    s.tri_zero, stream));
+    prof_begin(PH_TRANSPOSE);
+    DS_CHECK(tri_exchange(true));
+    prof_end(PH_TRANSPOSE);
+    for (auto &s : slabs) DS_CHECK(launch_tri_final(s.g, nt, kscale, cy, cx, pc, s.tri_brecv, s.w0, s.w1, stream));
     return 0;
 }
 
@@ -617,6 +710,11 @@ int Solver::poisson_all() {
         DS_CHECK(launch_dct_axis(py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, stream));
         DS_CHECK(launch_dct_axis(px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, stream));
     }
+    bool tri = multi() && tri_tsolve && world <= DS_MAX_WORLD;
+    for (auto &s : slabs) tri = tri && s.g.ntl <= TRI_EXTRA;
+    if (tri) {
+        DS_CHECK(poisson_t_tridiag());
+    } else {
     if (multi()) {       // timed on its own (inside "poisson") so that the scaling runs show what the all-to-alls cost
         prof_begin(PH_TRANSPOSE);
         DS_CHECK(transpose(true));
@@ -637,6 +735,7 @@ int Solver::poisson_all() {
         prof_begin(PH_TRANSPOSE);
         DS_CHECK(transpose(false));
         prof_end(PH_TRANSPOSE);
+    }
     }
     for (auto &s : slabs) {
         const Grid &g = s.g;

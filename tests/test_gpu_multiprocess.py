@@ -52,8 +52,10 @@ def _worker(rank, world, uid_hex, q):
         q.put((rank, traceback.format_exc() + repr(e)))
 
 
+@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_one_process_per_slab_matches_single_process(world):
+def test_one_process_per_slab_matches_single_process(world, tsolve, monkeypatch):
+    monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)        # inherited by the rank processes
     import multiprocessing as mp
     _build_fake()
     sys.path.insert(0, ROOT)

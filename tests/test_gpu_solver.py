@@ -183,11 +183,15 @@ def _run_slabs(rho0, rho1, nt, opts, nslabs, weight=None):
     return var, hist, sigma
 
 
+@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
 @pytest.mark.parametrize("case", ["dot2d_32x32x16", "dot2d_24x40x12", "dot2d_33x33x17", "dot1d_128x32", "wdot2d_32x32x16"])
 @pytest.mark.parametrize("nslabs", [2, 3, 4])
-def test_time_slabs_match_single_slab(case, nslabs, request):
+def test_time_slabs_match_single_slab(case, nslabs, tsolve, request, monkeypatch):
+    """Both ways of solving along t across slabs: partitioned tridiagonal systems (default: 4 numbers per mode over
+    the links) and slab <-> pencil transposes around the t-axis DCT (DOTSOCP_TSOLVE=dct)."""
     if "unfused" in request.node.name:
         pytest.skip("time slabs exist on the fused dataflow only")
+    monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)
     weight = None
     if case == "dot1d_128x32":
         rho0, rho1 = get_example_1d("gaussian", 128)
