@@ -102,8 +102,11 @@ class SlabInPALM:
     """State and iteration of ONE slab.  Inputs are the GLOBAL scaled level (var, model, opts as
     produced by oracle.driver.make_level); every rank cuts its own part."""
 
-    def __init__(self, var, opts, model, comm):
+    def __init__(self, var, opts, model, comm, tsolve="tridiag"):
+        """tsolve: how the Poisson solve crosses the slabs along t -- "tridiag": partitioned tridiagonal systems
+        (the device default, csrc/tri.hip), "dct": slab <-> pencil transposes around the t-axis DCT."""
         self.comm = comm
+        self.tsolve = tsolve
         r, w = comm.rank, comm.world
         ny, nx, nt = model.ny, model.nx, model.nt
         self.ny, self.nx, self.nt = ny, nx, nt
@@ -224,11 +227,129 @@ class SlabInPALM:
         ty = self.ay * (self.phi[1:, :, :] - self.phi[:-1, :, :])
         return t0, tx, ty
 
+    # -- the t direction by partitioned tridiagonal systems (mirrors csrc/tri.hip) ------------------------
+    def _delta(self, ap, t, n, first, last):
+        return ap + 2.0 - (1.0 if (first and t == 0) else 0.0) - (1.0 if (last and t == n - 1) else 0.0)
+
+    def _ends(self, ap, g, n, first, last):
+        """first and last entry of A^{-1} g for the slab block (eliminations from both ends); g: (modes, n)"""
+        piv, d = self._delta(ap, 0, n, first, last), g[:, 0].copy()
+        for t in range(1, n):
+            inv = 1.0 / piv
+            d = g[:, t] + d * inv
+            piv = self._delta(ap, t, n, first, last) - inv
+        last_v = d / piv
+        piv, d = self._delta(ap, n - 1, n, first, last), g[:, n - 1].copy()
+        for t in range(n - 2, -1, -1):
+            inv = 1.0 / piv
+            d = g[:, t] + d * inv
+            piv = self._delta(ap, t, n, first, last) - inv
+        return d / piv, last_v
+
+    def _poisson_t_tridiag(self, flat):
+        """flat: (ny*nx modes, ntl) after the y, x transforms -> the same array solved along t"""
+        ny, nx, nt, w, r = self.ny, self.nx, self.nt, self.comm.world, self.comm.rank
+        plane, n = ny * nx, self.ntl
+        beta = float((nt - 1) ** 2)
+        CX = (2.0 * (nx - 1) ** 2) * (1.0 - np.cos(np.pi * np.arange(nx) / nx))
+        CY = (2.0 * (ny - 1) ** 2) * (1.0 - np.cos(np.pi * np.arange(ny) / ny))
+        modes = np.arange(plane)
+        ap_all = (CY[modes % ny] + CX[modes // ny]) / beta
+        g = flat / (self.D ** 2 * beta)
+        Gf, Gl = self._ends(ap_all, g, n, self.first, self.last)
+        sizes = [slab_range(nt, w, j)[1] - slab_range(nt, w, j)[0] for j in range(w)]
+        nmax = max(sizes)
+        pieces = []
+        for j in range(w):                                      # 2 numbers per mode (+ the zero-mode line) to owner j
+            l0, l1 = pencil_range(plane, w, j)
+            extra = np.zeros(nmax)
+            if j == 0:
+                extra[:n] = g[0, :]
+            pieces.append((np.concatenate([Gf[l0:l1], Gl[l0:l1], extra]), (2 * (self.l1 - self.l0) + nmax,)))
+        got = self.comm.alltoall(pieces)
+        nl = self.l1 - self.l0
+        ap = ap_all[self.l0:self.l1]
+        A, B, al, ga = [None] * w, [None] * w, [None] * w, [None] * w
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for p in range(w):
+                first, last, npn = p == 0, p == w - 1, sizes[p]
+                e_first = np.zeros((nl, npn)); e_first[:, 0] = 1.0
+                e_last = np.zeros((nl, npn)); e_last[:, npn - 1] = 1.0
+                vf, vl = self._ends(ap, e_first, npn, first, last)
+                wf, wl = self._ends(ap, e_last, npn, first, last)
+                if first:
+                    vf, vl = 0.0 * vf, 0.0 * vl
+                if last:
+                    wf, wl = 0.0 * wf, 0.0 * wl
+                gf, gl = got[p][:nl], got[p][nl:2 * nl]
+                if p == 0:
+                    A[0], B[0], al[0], ga[0] = gf, wf, gl, wl
+                else:
+                    den = 1.0 - vf * ga[p - 1]
+                    A[p] = (gf + vf * al[p - 1]) / den
+                    B[p] = wf / den
+                    al[p] = gl + vl * (al[p - 1] + ga[p - 1] * A[p])
+                    ga[p] = wl + vl * ga[p - 1] * B[p]
+            back = [None] * w
+            Fnext = np.zeros(nl)
+            for p in range(w - 1, -1, -1):
+                F = A[p] + B[p] * Fnext
+                Lprev = al[p - 1] + ga[p - 1] * F if p > 0 else np.zeros(nl)
+                back[p] = np.concatenate([Lprev, Fnext, np.zeros(nmax)])
+                Fnext = F
+        if self.l0 == 0 and nl > 0:                              # the singular (0, 0) mode, whole line
+            line = np.concatenate([got[p][2 * nl:2 * nl + sizes[p]] for p in range(w)])
+            gbar = line.mean()
+            x = np.zeros(nt)
+            for t in range(nt - 1):
+                gt = line[t] - gbar
+                x[t + 1] = x[t] - gt if t == 0 else 2.0 * x[t] - x[t - 1] - gt
+            x = x - x.mean() + beta * gbar
+            o = 0
+            for p in range(w):
+                back[p][0] = back[p][nl] = 0.0
+                back[p][2 * nl:2 * nl + sizes[p]] = x[o:o + sizes[p]]
+                o += sizes[p]
+        # the reply of owner j has the length of what was sent to it
+        shapes = [(2 * (pencil_range(plane, w, j)[1] - pencil_range(plane, w, j)[0]) + nmax,) for j in range(w)]
+        ret = self.comm.alltoall([(back[j], shapes[j]) for j in range(w)])
+        xl, xr = np.zeros(plane), np.zeros(plane)
+        zero_line = None
+        for j in range(w):
+            l0, l1 = pencil_range(plane, w, j)
+            xl[l0:l1], xr[l0:l1] = ret[j][:l1 - l0], ret[j][l1 - l0:2 * (l1 - l0)]
+            if j == 0:
+                zero_line = ret[j][2 * (l1 - l0):2 * (l1 - l0) + n]
+        # local Thomas solve with the neighbours' interface values on the right-hand side
+        gt = g.copy()
+        gt[:, 0] += xl
+        gt[:, n - 1] += xr
+        pinv = np.zeros((plane, n))
+        xs = np.zeros((plane, n))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            piv = self._delta(ap_all, 0, n, self.first, self.last)
+            d = gt[:, 0].copy()
+            inv = 1.0 / piv
+            xs[:, 0], pinv[:, 0] = d * inv, inv
+            for t in range(1, n):
+                d = gt[:, t] + d * inv
+                piv = self._delta(ap_all, t, n, self.first, self.last) - inv
+                inv = 1.0 / piv
+                xs[:, t], pinv[:, t] = d * inv, inv
+            for t in range(n - 2, -1, -1):
+                xs[:, t] = xs[:, t] + pinv[:, t] * xs[:, t + 1]
+        xs[0, :] = zero_line
+        return xs
+
     def _poisson(self, rhs):
-        """dct over y, x on the slab; slabs -> pencils; dct_t, ./kernel, idct_t; pencils -> slabs; idct x, y"""
+        """dct over y, x on the slab; along t either partitioned tridiagonal systems or slabs -> pencils, dct_t,
+        ./kernel, idct_t, pencils -> slabs; idct x, y"""
         ny, nx, nt, w = self.ny, self.nx, self.nt, self.comm.world
         a = sfft.dct(sfft.dct(rhs, axis=0, norm="ortho"), axis=1, norm="ortho")
         flat = a.reshape((ny * nx, self.ntl), order="F")
+        if self.tsolve == "tridiag" and w > 1:
+            a = self._poisson_t_tridiag(flat).reshape((ny, nx, self.ntl), order="F")
+            return sfft.idct(sfft.idct(a, axis=1, norm="ortho"), axis=0, norm="ortho")
         pieces = []
         for j in range(w):
             l0, l1 = pencil_range(ny * nx, w, j)

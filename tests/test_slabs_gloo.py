@@ -68,7 +68,7 @@ def test_slab_ranges_cover_grid():
         assert all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, tsolve):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -76,7 +76,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         var, model, o = _level()
-        slab = SlabInPALM(var, o, model, GlooComm()).run()
+        slab = SlabInPALM(var, o, model, GlooComm(), tsolve=tsolve).run()
         _check(slab, _reference())
         q.put((rank, "ok"))
     except Exception as e:            # noqa: BLE001
@@ -86,15 +86,18 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_slab_oracle_gloo(world):
+def test_slab_oracle_gloo(world, tsolve):
+    """The time-slab algorithm restated on the CPU, one process per slab over gloo, with both ways of crossing the
+    slabs in the Poisson solve (partitioned tridiagonal systems = the device default; transposes)."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tsolve)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
