@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
     const i64 x = (i64)blk.y * XB + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
     const i64 yc = inb ? y : 0, xc = inb ? x : 0;      // clamped coordinates keep out-of-tile lanes harmless
-    const i64 t0 = (i64)blk.z * a.TC;
+    const i64 t0 = ((i64)blk.z + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
     const bool lastChunk = (t1 == g.ncl);
     constexpr bool GATHER = (MODE < 2 || MODE == 4);
@@ -121,6 +121,11 @@ bool tile_xcd_remap(const Grid &g) {
     return (g.ny % 16) != 0;
 }
 
+bool cone_split_enabled() {
+    static const bool on = !(getenv("DOTSOCP_SPLIT_CONE") && atoi(getenv("DOTSOCP_SPLIT_CONE")) == 0);
+    return on;
+}
+
 int fused_geometry(const Grid &g, FusedGeom &fg) {
     fg.XB = 4;
     fg.nyblk = (g.ny + 63) / 64;
@@ -130,6 +135,8 @@ int fused_geometry(const Grid &g, FusedGeom &fg) {
     static const i64 target = getenv("DOTSOCP_CONE_BLOCKS") ? atoll(getenv("DOTSOCP_CONE_BLOCKS")) : 2048;
     i64 chunks = (target + tiles - 1) / tiles;
     if (chunks < 1) chunks = 1;
+    // a slab of a time-slab decomposition: at least two chunks (see cone_split_enabled)
+    if (!(g.first && g.last) && cone_split_enabled() && chunks < 2 && g.ncl >= 12) chunks = 2;
     i64 TC = (g.ncl + chunks - 1) / chunks;
     if (TC < 8) TC = 8;
     if (TC > g.ncl) TC = g.ncl;
@@ -142,11 +149,14 @@ int fused_geometry(const Grid &g, FusedGeom &fg) {
 }
 
 int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
-                      hipStream_t st) {
+                      hipStream_t st, i64 z0, i64 zcount) {
     if (g.Nz <= 0) return 0;
+    if (zcount < 0) zcount = fg.chunks - z0;
+    if (z0 < 0 || zcount <= 0 || z0 + zcount > fg.chunks) return 0;
     a.TC = fg.TC;
+    a.z0 = (int)z0;
     a.xcd = tile_xcd_remap(g) ? 1 : 0;
-    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
+    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(64, 4);
     switch (mode) {
         case 0: hipLaunchKernelGGL((k_cone_fused<0, 4>), grid, blk, 0, st, g, c, a); break;

@@ -66,14 +66,19 @@ struct FusedArgs {
     int bpend;
     double bmul, bdiv;
     int xcd;                // permute the tile order so that y-neighbouring tiles share an XCD (device_utils.h)
+    int z0;                 // first chunk of this launch (launch_cone_fused can launch a range of chunks)
 };
 // rows that are not a multiple of 16 doubles (128 bytes): neighbouring tiles share cache lines (2^k+1 grids)
 bool tile_xcd_remap(const Grid &g);
 int fused_geometry(const Grid &g, FusedGeom &fg);
 // mode 0: projection + gather; 1: deferred beta update + projection + gather; 2: materialise beta and z;
 // 3: z only, from (q_old, beta_in); 4: deferred beta update + gather of (z^k + beta^k) (PALM's first q-step)
+// [z0, z0 + zcount) = the chunks to launch (zcount < 0: all from z0 on); chunks are independent of each other
 int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
-                      hipStream_t st);
+                      hipStream_t st, i64 z0 = 0, i64 zcount = -1);
+// time-slab mode: split every slab's cone pass into >= 2 chunks so that the chunks in front of the last one --
+// which alone reads the q halo -- can start before the halo has arrived (DOTSOCP_SPLIT_CONE=0 disables)
+bool cone_split_enabled();
 
 // ---------------- acc.hip (acc-ADMM loop) ----------------
 struct AccArgs {

@@ -74,7 +74,7 @@ struct Solver {
     i64 ny = 0, nx = 0, nt = 0;     // internal dims (1-D problems: ny = nx1d, nx = 1)
     hipStream_t stream = nullptr;      // main stream: everything but the overlapped cone pass; all communication
     hipStream_t stream_z = nullptr;    // cone pass when it overlaps the phi step
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_halo = nullptr;
     bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process
     int world = 1;                  // total number of slabs
@@ -143,7 +143,7 @@ struct Solver {
     int step(bool *brk);
     int rescale_block();
     int phase_phi();
-    int phase_z(hipStream_t st);
+    int phase_z(hipStream_t st, int part = 0);   // part 0: all chunks; 1: all but the last chunk; 2: the last chunk
     int phase_z_tails();
     int phase_q();
     int phase_mult();
@@ -159,6 +159,7 @@ struct Solver {
     int poisson_all();
     int transpose(bool forward);
     int exchange_q_halo(bool with_u0);
+    int ensure_halo();       // run the q-halo exchange the last q-step left pending (halo_pending)
     int exchange_u0_tail();
     int group_begin();
     int group_end();
@@ -169,6 +170,9 @@ struct Solver {
     int poisson_t_tridiag();
     bool qrhs = true;        // DOTSOCP_QRHS=0: separate q-step and rhs kernels
     bool rhs_valid = false;  // w0 holds A'(w.*q - alpha) + c of the current iterate (left there by the q-step)
+    // the q halo / u0 tail of the newest iterate have not been exchanged yet: step() issues the exchange behind the
+    // fork so that the cone chunks that do not read the halo overlap it; every other reader calls ensure_halo()
+    bool halo_pending = false;
     bool u0_fresh = false;   // u0_prev holds w.*q0 - alpha0 of the CURRENT iterate of the left neighbour
     // every slab with a neighbour in direction `dir` (+1 right, -1 left) sends `count` doubles
     // from src(slab) to dst(neighbour)

@@ -58,6 +58,7 @@ Solver::~Solver() {
     for (auto e : event_pool) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_halo) (void)hipEventDestroy(ev_halo);
     if (stream_z) (void)hipStreamDestroy(stream_z);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -115,6 +116,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     DS_HIP(hipStreamCreateWithFlags(&stream_z, hipStreamNonBlocking));
     DS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     DS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    DS_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
     overlap = nslabs > 1;                         // pays when there is communication to hide
     if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_QRHS")) qrhs = (atoi(e) != 0);
@@ -291,6 +293,12 @@ int Solver::exchange_q_halo(bool with_u0) {
     DS_CHECK(group_end());
     prof_end(PH_COMM);
     return 0;
+}
+
+int Solver::ensure_halo() {
+    if (!halo_pending) return 0;
+    halo_pending = false;
+    return exchange_q_halo(true);
 }
 
 // slabs [y][x][t_local] <-> pencils [columns l0..l0+nl)[all t]; data in w0 resp. pencil
@@ -746,8 +754,7 @@ int Solver::poisson_all() {
 }
 
 int Solver::phase_phi() {
-    const i64 plane = ny * nx;
-    (void)plane;
+    DS_CHECK(ensure_halo());
     if (multi() && !u0_fresh) {      // normally shipped with the q halo at the end of the previous iteration
         prof_begin(PH_COMM);
         DS_CHECK(exchange_u0_tail());
@@ -771,7 +778,8 @@ int Solver::phase_phi() {
 
 // The cone pass needs q^k and beta only -- not phi^{k+1} -- so it may run on `st` = stream_z
 // concurrently with the phi step (rhs, Poisson solve and, in time-slab mode, its transposes).
-int Solver::phase_z(hipStream_t st) {
+int Solver::phase_z(hipStream_t st, int part) {
+    if (part != 1) DS_CHECK(ensure_halo());     // the last chunk reads the q halo (part 1 never does)
     if (!fused) {
         prof_begin(PH_PROJ, st);
         for (auto &s : slabs) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, st));
@@ -781,7 +789,7 @@ int Solver::phase_z(hipStream_t st) {
     const int ph = deferred ? PH_FUSED_B : PH_FUSED_A;
     z_valid = false;          // the fused pass forms z^{k+1} in registers only
     z_prev_ok = false;        // ... and (mode B) overwrites the kept beta^{k-1}
-    prof_begin(ph, st);
+    if (part != 2) prof_begin(ph, st);
     for (auto &s : slabs) {
         FusedArgs a{};
         a.q = s.q;
@@ -790,16 +798,19 @@ int Solver::phase_z(hipStream_t st) {
         a.sy = s.sy;
         a.beta_in = s.beta;
         set_pending(a);
+        const i64 z0 = (part == 2) ? s.fg.chunks - 1 : 0;
+        const i64 zc = (part == 0) ? s.fg.chunks : ((part == 1) ? s.fg.chunks - 1 : 1);
         if (deferred) {
             // beta^k = beta^{k-1} + tau (z^k - BF q^k - d) folded into this iteration's projection
             a.q_old = s.q_old;
             a.beta_out = s.beta2;
-            DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, st));
-            std::swap(s.beta, s.beta2);
+            DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, st, z0, zc));
+            if (part != 1) std::swap(s.beta, s.beta2);
         } else {
-            DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, st));
+            DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, st, z0, zc));
         }
     }
+    if (part == 1) return 0;
     prof_end(ph, st);
     if (deferred) bpend = false;      // mode B rewrote beta with the scaling applied
     return 0;
@@ -844,7 +855,9 @@ int Solver::phase_q() {
     }
     prof_end(PH_QSTEP);
     rhs_valid = fused && qrhs;
-    DS_CHECK(exchange_q_halo(true));
+    // the halo exchange waits for the next consumer: the next step() runs it beside the first cone chunks
+    if (multi() && fused && overlap && cone_split_enabled()) halo_pending = true;
+    else DS_CHECK(exchange_q_halo(true));
     return 0;
 }
 
@@ -863,6 +876,7 @@ int Solver::phase_mult() {
 // 212-215) so that beta, z are the iterates the KKT block, the rescale block and the outputs see.
 int Solver::materialise() {
     if (!fused || !deferred) return 0;
+    DS_CHECK(ensure_halo());
     prof_begin(PH_MATERIALISE);
     for (auto &s : slabs) {
         FusedArgs a{};
@@ -889,6 +903,7 @@ int Solver::ensure_z() {
         set_error("internal: z cannot be regenerated");
         return DOTSOCP_ESTATE;
     }
+    DS_CHECK(ensure_halo());
     prof_begin(PH_MATERIALISE);
     for (auto &s : slabs) {
         FusedArgs a{};
@@ -907,6 +922,7 @@ int Solver::ensure_z() {
 }
 
 int Solver::kkt_sums(double *S) {
+    DS_CHECK(ensure_halo());
     KktCoef k;
     k.sigma = sigma;
     k.kappa = sigma * cScale * D;
@@ -1131,8 +1147,24 @@ int Solver::step(bool *brk) {
     if (method == DOTSOCP_METHOD_PALM) return palm_step(brk);
     it += 1;
     DS_CHECK(rescale_block());
-    if (overlap) {
+    bool split = overlap && fused && halo_pending;
+    for (auto &s : slabs) split = split && s.fg.chunks >= 2;
+    if (split) {
+        // as below, and the q halo / u0 tail of the last q-step travel (main stream) while stream_z works on the
+        // cone chunks that do not read the halo; only the last chunk of every slab waits for it
+        DS_HIP(hipEventRecord(ev_fork, stream));
+        DS_CHECK(ensure_halo());
+        DS_HIP(hipEventRecord(ev_halo, stream));
+        DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
+        DS_CHECK(phase_z(stream_z, 1));
+        DS_HIP(hipStreamWaitEvent(stream_z, ev_halo, 0));
+        DS_CHECK(phase_z(stream_z, 2));
+        DS_HIP(hipEventRecord(ev_join, stream_z));
+        DS_CHECK(phase_phi());
+        DS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    } else if (overlap) {
         // fork: cone pass on stream_z beside the phi step on the main stream, join before the q-step
+        DS_CHECK(ensure_halo());
         DS_HIP(hipEventRecord(ev_fork, stream));
         DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
         DS_CHECK(phase_z(stream_z));
@@ -1165,6 +1197,7 @@ int Solver::run(i64 n_iters, i64 *done) {
         if (brk) stopped = true;
         ++n;
     }
+    DS_CHECK(ensure_halo());          // callers between run() calls see exchanged halos
     DS_HIP(hipStreamSynchronize(stream));
     DS_CHECK(prof_flush());
     if (done) *done = n;

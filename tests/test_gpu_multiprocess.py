@@ -15,7 +15,7 @@ FAKE_DIR = os.path.join(ROOT, "tests", "fake_rccl")
 FAKE_SO = os.path.join(FAKE_DIR, "libfake_rccl.so")
 pytestmark = pytest.mark.gpu
 
-NY, NX, NT, K = 32, 24, 16, 25
+NY, NX, K = 32, 24, 25
 
 
 def _build_fake():
@@ -24,7 +24,7 @@ def _build_fake():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-Wno-unused-result", "-o", FAKE_SO, src])
 
 
-def _worker(rank, world, uid_hex, q):
+def _worker(rank, world, uid_hex, q, NT):
     os.environ["DOTSOCP_RCCL_LIB"] = FAKE_SO
     sys.path.insert(0, ROOT)
     try:
@@ -52,9 +52,11 @@ def _worker(rank, world, uid_hex, q):
         q.put((rank, traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
-@pytest.mark.parametrize("world", [2, 4])
-def test_one_process_per_slab_matches_single_process(world, tsolve, monkeypatch):
+# nt = 32 on two ranks / 64 on four: 15-16 cell layers per slab = two cone chunks, i.e. the path where the q-halo exchange runs beside
+# the first chunk (Solver::step, split branch); nt = 16: one chunk per slab, exchange in front of the cone pass
+@pytest.mark.parametrize("world,tsolve,NT", [(2, "tridiag", 16), (2, "dct", 16), (4, "tridiag", 16), (4, "dct", 16),
+                                             (2, "tridiag", 32), (2, "dct", 32), (4, "tridiag", 64)])
+def test_one_process_per_slab_matches_single_process(world, tsolve, NT, monkeypatch):
     monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)        # inherited by the rank processes
     import multiprocessing as mp
     _build_fake()
@@ -79,7 +81,7 @@ def test_one_process_per_slab_matches_single_process(world, tsolve, monkeypatch)
     uid = D.capi.rccl_unique_id()
     ctx = mp.get_context("spawn")
     qu = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu, NT)) for r in range(world)]
     for p in procs:
         p.start()
     results = [qu.get(timeout=300) for _ in procs]
