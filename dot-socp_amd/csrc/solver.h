@@ -145,7 +145,7 @@ struct Solver {
     int phase_phi();
     int phase_z(hipStream_t st, int part = 0);   // part 0: all chunks; 1: all but the last chunk; 2: the last chunk
     int phase_z_tails();
-    int phase_q();
+    int phase_q(int part = 0);   // part 0: whole q-step; 1: the middle chunks on stream_z; 2: first + last chunk, then finish
     int phase_mult();
     int materialise();
     int kkt_sums(double *S);

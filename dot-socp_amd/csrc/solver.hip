@@ -834,8 +834,9 @@ int Solver::phase_z_tails() {
     return 0;
 }
 
-int Solver::phase_q() {
-    prof_begin(PH_QSTEP);
+int Solver::phase_q(int part) {
+    hipStream_t st = (part == 1) ? stream_z : stream;
+    if (part != 1) prof_begin(PH_QSTEP);
     for (auto &s : slabs) {
         if (!fused) {
             DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
@@ -843,17 +844,26 @@ int Solver::phase_q() {
             // q^{k+1} goes to the buffer that held q^{k-1}; q^k is kept for the deferred beta update
             if (qrhs) {
                 // ... and the right-hand side of the next phi-step is formed in the same pass (alpha ping-pongs)
-                DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.c,
-                                          s.q_old, s.alpha, s.alpha2, s.w0, stream));
-                std::swap(s.alpha, s.alpha2);
+                const i64 C = qstep_rhs_chunks(s.g, s.fg);
+                for (int leg = 0; leg < 2; ++leg) {
+                    i64 z0 = 0, zc = C;
+                    if (part == 1) { z0 = 1; zc = C - 2; if (leg) break; }
+                    else if (part == 2) { z0 = leg ? C - 1 : 0; zc = 1; }
+                    else if (leg) break;
+                    DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.c,
+                                              s.q_old, s.alpha, s.alpha2, s.w0, st, z0, zc));
+                }
+                if (part != 1) std::swap(s.alpha, s.alpha2);
             } else {
                 DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by,
                                             s.q_old, s.alpha, stream));
             }
-            std::swap(s.q, s.q_old);
+            if (part != 1) std::swap(s.q, s.q_old);
         }
     }
+    if (part == 1) return 0;
     prof_end(PH_QSTEP);
+    if (part == 2) DS_HIP(hipStreamWaitEvent(stream, ev_join, 0));     // the middle chunks (stream_z)
     rhs_valid = fused && qrhs;
     // the halo exchange waits for the next consumer: the next step() runs it beside the first cone chunks
     if (multi() && fused && overlap && cone_split_enabled()) halo_pending = true;
@@ -1175,8 +1185,21 @@ int Solver::step(bool *brk) {
         DS_CHECK(phase_phi());
         DS_CHECK(phase_z(stream));
     }
-    DS_CHECK(phase_z_tails());
-    DS_CHECK(phase_q());
+    bool split_q = overlap && fused && qrhs && multi() && cone_split_enabled();
+    for (auto &s : slabs) split_q = split_q && qstep_rhs_chunks(s.g, s.fg) >= 3;
+    if (split_q) {
+        // the chunks of the q-step that need neither neighbour run on stream_z while the phi head and the adjoint
+        // tails travel on the main stream; the first and the last chunk follow the exchange
+        DS_HIP(hipEventRecord(ev_fork, stream));                 // phi^{k+1} and the cone pass are complete
+        DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
+        DS_CHECK(phase_q(1));
+        DS_HIP(hipEventRecord(ev_join, stream_z));
+        DS_CHECK(phase_z_tails());
+        DS_CHECK(phase_q(2));
+    } else {
+        DS_CHECK(phase_z_tails());
+        DS_CHECK(phase_q());
+    }
     DS_CHECK(phase_mult());
     const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
     // with one slab per process a per-rank clock could split the ranks: see kkt_block()

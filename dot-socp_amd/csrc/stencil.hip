@@ -316,7 +316,7 @@ __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double 
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
-    i64 TC;
+    i64 TC, z0;        // layers per chunk, first chunk of this launch
     // VAR 2 (acc-ADMM, Halpern step folded in): q_out receives the raw q^+ (the cone pass needs it), the
     // extrapolated q goes to q_state in place and the extrapolated alpha to alpha_out
     double *q_state;
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     const i64 y = (i64)blockIdx.x * TILE_Y + lane;
     const i64 x = (i64)blockIdx.y * TILE_X + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
-    const i64 t0 = (i64)blockIdx.z * a.TC;
+    const i64 t0 = ((i64)blockIdx.z + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ntl) ? t0 + a.TC : g.ntl;
     auto bx_q2 = [&](i64 yy, i64 xx, i64 tl, i64 e) {
         double q2 = a.q2v[e];
@@ -444,16 +444,17 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     }
 }
 
-static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st);
+static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st,
+                                i64 z0 = 0, i64 zcount = -1);
 
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
-                     double *rhs, hipStream_t st) {
+                     double *rhs, hipStream_t st, i64 z0, i64 zcount) {
     QRhsArgs a{};
     a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.weight = weight; a.tail_bx = tail_bx; a.tail_by = tail_by;
     a.cvec = cvec; a.alpha_in = alpha_in; a.q_out = q_out; a.alpha_out = alpha_out; a.rhs = rhs;
-    return launch_qstep_rhs_var(0, g, c, fg, a, st);
+    return launch_qstep_rhs_var(0, g, c, fg, a, st, z0, zcount);
 }
 
 // var 1 / 2: the acc-ADMM flavours (see k_qstep_rhs); `acc` carries the Halpern weights and the extra arrays of var 2
@@ -469,7 +470,7 @@ int launch_qstep_rhs_acc(int var, const Grid &g, const LoopCoef &c, const FusedG
     return launch_qstep_rhs_var(var, g, c, fg, a, st);
 }
 
-static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st) {
+i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TCout) {
     // short chunks of time layers (measured at 1024x1024x128: 3.45 ms with 8-layer chunks, 4.2 ms with one chunk per
     // tile -- the march is latency-bound per workgroup); each extra chunk recomputes one cell
     const i64 tiles = fg.nyblk * fg.nxblk;
@@ -477,9 +478,27 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     i64 chunks = (target + tiles - 1) / tiles;
     i64 TC = (g.ntl + chunks - 1) / chunks;
     if (TC < 8) TC = 8;
+    // a slab of a time-slab decomposition: at least four chunks, so that the two in the middle -- which need neither
+    // neighbour -- can run while the phi head and the adjoint tails travel (Solver::step)
+    if (!(g.first && g.last) && cone_split_enabled() && g.ntl >= 12) {
+        const i64 quarter = (g.ntl + 3) / 4;
+        if (TC > quarter) TC = quarter < 4 ? 4 : quarter;
+    }
     if (TC > g.ntl) TC = g.ntl;
+    if (TC < 1) TC = 1;
+    if (TCout) *TCout = TC;
+    return (g.ntl + TC - 1) / TC;
+}
+
+static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st,
+                                i64 z0, i64 zcount) {
+    i64 TC = 1;
+    const i64 chunks = qstep_rhs_chunks(g, fg, &TC);
+    if (zcount < 0) zcount = chunks - z0;
+    if (z0 < 0 || zcount <= 0 || z0 + zcount > chunks) return 0;
     a.TC = TC;
-    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)((g.ntl + TC - 1) / TC));
+    a.z0 = z0;
+    dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(TILE_Y, TILE_X);
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
     if (a.weight) {
