@@ -1191,10 +1191,10 @@ int Solver::step(bool *brk) {
         // the chunks of the q-step that need neither neighbour run on stream_z while the phi head and the adjoint
         // tails travel on the main stream; the first and the last chunk follow the exchange
         DS_HIP(hipEventRecord(ev_fork, stream));                 // phi^{k+1} and the cone pass are complete
+        DS_CHECK(phase_z_tails());                               // enqueued first: the exchange gets its CUs at once
         DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
         DS_CHECK(phase_q(1));
         DS_HIP(hipEventRecord(ev_join, stream_z));
-        DS_CHECK(phase_z_tails());
         DS_CHECK(phase_q(2));
     } else {
         DS_CHECK(phase_z_tails());
