@@ -18,6 +18,8 @@
 #include "device_utils.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace dotsocp {
 
 struct TriGeom {
@@ -201,6 +203,109 @@ __global__ void __launch_bounds__(256) k_tri_final(TriGeom g, const double *__re
     }
 }
 
+
+// Register-resident flavours for short slabs (ntl <= NTL): the column of a mode is read ONCE into registers, both
+// eliminations (k_tri_local) resp. the whole Thomas solve (k_tri_final) run there, and the result is written once --
+// 1 and 2 passes over the slab instead of 2 and 6.  Same operations in the same order as the kernels above.
+template <int NTL>
+__global__ void __launch_bounds__(256) k_tri_local_reg(TriGeom g, const double *__restrict__ r, double *__restrict__ send) {
+    const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (m >= g.plane) return;
+    const double ap = tri_aprime(g, m);
+    const double sc = 1.0 / (g.kscale * g.beta);
+    const int n = (int)g.ntl;
+    double G[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) G[t] = (t < n) ? r[m + g.plane * t] * sc : 0.0;
+    double piv = tri_delta(ap, 0, n, g.first, g.last), d = G[0];
+#pragma unroll
+    for (int t = 1; t < NTL; ++t) {
+        if (t < n) {
+            const double inv = 1.0 / piv;
+            d = G[t] + d * inv;
+            piv = tri_delta(ap, t, n, g.first, g.last) - inv;
+        }
+    }
+    const double Gl = d / piv;
+#pragma unroll
+    for (int t = NTL - 1; t >= 0; --t) {
+        if (t == n - 1) {
+            piv = tri_delta(ap, t, n, g.first, g.last);
+            d = G[t];
+        } else if (t < n - 1) {
+            const double inv = 1.0 / piv;
+            d = G[t] + d * inv;
+            piv = tri_delta(ap, t, n, g.first, g.last) - inv;
+        }
+    }
+    const double Gf = d / piv;
+    const int j = tri_owner(g.pc, m, g.plane);
+    const i64 off = tri_msg_off(g.pc, j), w = g.pc.cut[j + 1] - g.pc.cut[j];
+    send[off + (m - g.pc.cut[j])] = Gf;
+    send[off + w + (m - g.pc.cut[j])] = Gl;
+    if (m == 0) {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+            if (t < n) send[off + 2 * w + t] = G[t];
+    }
+}
+
+template <int NTL>
+__global__ void __launch_bounds__(256) k_tri_final_reg(TriGeom g, const double *__restrict__ back, double *__restrict__ x) {
+    const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (m >= g.plane) return;
+    const int n = (int)g.ntl;
+    const int j = tri_owner(g.pc, m, g.plane);
+    const i64 off = tri_msg_off(g.pc, j), w = g.pc.cut[j + 1] - g.pc.cut[j];
+    if (m == 0) {
+        for (int t = 0; t < n; ++t) x[g.plane * t] = back[off + 2 * w + t];
+        return;
+    }
+    const double ap = tri_aprime(g, m);
+    const double sc = 1.0 / (g.kscale * g.beta);
+    const double xl = back[off + (m - g.pc.cut[j])], xr = back[off + w + (m - g.pc.cut[j])];
+    double X[NTL], Q[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) X[t] = (t < n) ? x[m + g.plane * t] : 0.0;
+    double piv = tri_delta(ap, 0, n, g.first, g.last);
+    double d = X[0] * sc + xl + ((n == 1) ? xr : 0.0);
+    double inv = 1.0 / piv;
+    X[0] = d * inv;
+    Q[0] = inv;
+#pragma unroll
+    for (int t = 1; t < NTL; ++t) {
+        Q[t] = 0.0;
+        if (t < n) {
+            double gt = X[t] * sc;
+            if (t == n - 1) gt += xr;
+            d = gt + d * inv;
+            piv = tri_delta(ap, t, n, g.first, g.last) - inv;
+            inv = 1.0 / piv;
+            X[t] = d * inv;
+            Q[t] = inv;
+        }
+    }
+    double xn = 0.0;
+#pragma unroll
+    for (int t = NTL - 1; t >= 0; --t) {
+        if (t == n - 1) {
+            xn = X[t];
+        } else if (t < n - 1) {
+            xn = X[t] + Q[t] * xn;
+            X[t] = xn;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+        if (t < n) x[m + g.plane * t] = X[t];
+}
+
+static int tri_reg_width(i64 ntl) {
+    static const bool on = !(getenv("DOTSOCP_TRI_REG") && atoi(getenv("DOTSOCP_TRI_REG")) == 0);
+    if (!on) return 0;
+    return ntl <= 16 ? 16 : (ntl <= 32 ? 32 : 0);
+}
+
 static TriGeom make_geom(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc) {
     TriGeom t{};
     t.ny = g.ny; t.plane = g.plane; t.ntl = g.ntl;
@@ -215,7 +320,11 @@ static TriGeom make_geom(const Grid &g, i64 nt, double kscale, const double *cy,
 int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                      const double *r, double *send, hipStream_t st) {
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
-    hipLaunchKernelGGL(k_tri_local, dim3((unsigned)((g.plane + 255) / 256)), dim3(256), 0, st, t, r, send);
+    const dim3 grid((unsigned)((g.plane + 255) / 256));
+    const int rw = tri_reg_width(g.ntl);
+    if (rw == 16) hipLaunchKernelGGL(k_tri_local_reg<16>, grid, dim3(256), 0, st, t, r, send);
+    else if (rw == 32) hipLaunchKernelGGL(k_tri_local_reg<32>, grid, dim3(256), 0, st, t, r, send);
+    else hipLaunchKernelGGL(k_tri_local, grid, dim3(256), 0, st, t, r, send);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -236,7 +345,11 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
 int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                      const double *back, double *x, double *qinv, hipStream_t st) {
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
-    hipLaunchKernelGGL(k_tri_final, dim3((unsigned)((g.plane + 255) / 256)), dim3(256), 0, st, t, back, x, qinv);
+    const dim3 grid((unsigned)((g.plane + 255) / 256));
+    const int rw = tri_reg_width(g.ntl);
+    if (rw == 16) hipLaunchKernelGGL(k_tri_final_reg<16>, grid, dim3(256), 0, st, t, back, x);
+    else if (rw == 32) hipLaunchKernelGGL(k_tri_final_reg<32>, grid, dim3(256), 0, st, t, back, x);
+    else hipLaunchKernelGGL(k_tri_final, grid, dim3(256), 0, st, t, back, x, qinv);
     DS_HIP(hipGetLastError());
     return 0;
 }
