@@ -184,7 +184,10 @@ def _run_slabs(rho0, rho1, nt, opts, nslabs, weight=None):
 
 
 @pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
-@pytest.mark.parametrize("case", ["dot2d_32x32x16", "dot2d_24x40x12", "dot2d_33x33x17", "dot1d_128x32", "wdot2d_32x32x16"])
+# the x48 / x49 / 1-D cases have >= 12 time layers per slab: the cone pass and the q-step then run in chunks around the
+# halo exchanges (Solver::step, split branches); the shorter ones take the unsplit branches
+@pytest.mark.parametrize("case", ["dot2d_32x32x16", "dot2d_24x40x12", "dot2d_33x33x17", "dot1d_128x32", "wdot2d_32x32x16",
+                                  "dot2d_33x33x49", "wdot2d_32x32x48"])
 @pytest.mark.parametrize("nslabs", [2, 3, 4])
 def test_time_slabs_match_single_slab(case, nslabs, tsolve, request, monkeypatch):
     """Both ways of solving along t across slabs: partitioned tridiagonal systems (default: 4 numbers per mode over
