@@ -230,6 +230,27 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     if (!getenv("DOTSOCP_OVERLAP")) overlap = wd > 1;
     DS_CHECK(ensure_alloc());
     DS_HIP(hipStreamSynchronize(stream));
+    if (wd > 1) {
+        // handshake: the communicator spans `wd` ranks and the neighbours are the ranks this slab expects (also opens
+        // the neighbour connections before the first timed iteration)
+        double h[4] = {1.0, (double)rk, 0.0, -1.0};
+        double *d = nullptr;
+        DS_CHECK(dmalloc(&d, 4));
+        DS_HIP(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, stream));
+        DS_NCCL(api.AllReduce(d, d + 2, 1, ncclDouble, ncclSum, comm, stream));
+        DS_NCCL(api.GroupStart());
+        if (rk + 1 < wd) DS_NCCL(api.Send(d + 1, 1, ncclDouble, rk + 1, comm, stream));
+        if (rk > 0) DS_NCCL(api.Recv(d + 3, 1, ncclDouble, rk - 1, comm, stream));
+        DS_NCCL(api.GroupEnd());
+        DS_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, stream));
+        DS_HIP(hipStreamSynchronize(stream));
+        dfree(d);
+        if (h[2] != (double)wd || (rk > 0 && h[3] != (double)(rk - 1))) {
+            set_error("RCCL handshake failed: %g ranks answered (expected %d), left neighbour says %g (expected %d)", h[2], wd,
+                      h[3], rk - 1);
+            return DOTSOCP_ECOMM;
+        }
+    }
     return 0;
 }
 
