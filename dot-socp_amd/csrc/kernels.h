@@ -134,7 +134,7 @@ int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, do
 // PALM (solver_socp_PALM.m:196-200,137): first q-step without the alpha update; tmp_q = A phi in q layout
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                             const double *sx, const double *sy, const double *cvec, double *q_out, const double *alpha,
-                            double *rhs, hipStream_t st);
+                            double *rhs, hipStream_t st, const double *tail_bx = nullptr, const double *tail_by = nullptr);
 int launch_grad(const Grid &g, const LoopCoef &c, const double *phi, double *out, hipStream_t st);
 // time-slab mode: complete the adjoint sums of the last owned cell for the right neighbour (values times sf)
 int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,

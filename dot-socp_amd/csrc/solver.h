@@ -178,6 +178,7 @@ struct Solver {
     // from src(slab) to dst(neighbour)
     typedef std::function<double *(Slab &)> Sel;
     int shift(int dir, const Sel &src, const Sel &dst, i64 count);
+    int shift_edge_halo(const Sel &base);      // first owned bx / by layers of base(s) -> halo layer of the left slab
     i64 field_len(int field) const;
 
     // ---- loop variants (include/dotsocp.h: DOTSOCP_METHOD_*) ----

@@ -277,6 +277,15 @@ int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
     return 0;
 }
 
+int Solver::shift_edge_halo(const Sel &base) {
+    if (!multi()) return 0;
+    DS_CHECK(shift(-1, [&](Slab &s) { return base(s) + s.g.offBx; },
+                   [&](Slab &s) { return base(s) + s.g.offBx + s.g.bxLayer * s.g.ntl; }, slabs[0].g.bxLayer));
+    DS_CHECK(shift(-1, [&](Slab &s) { return base(s) + s.g.offBy; },
+                   [&](Slab &s) { return base(s) + s.g.offBy + s.g.byLayer * s.g.ntl; }, slabs[0].g.byLayer));
+    return 0;
+}
+
 // Several shift() calls issued as ONE RCCL group (nested groups are legal): traffic to the left and
 // to the right neighbour then shares the bidirectional links instead of queueing behind each other.
 int Solver::group_begin() {
@@ -676,7 +685,7 @@ int Solver::begin_method(const dotsocp_opts *o, int m, const dotsocp_acc_opts *a
     if (m == DOTSOCP_METHOD_INPALM) return begin(o);
     DS_ARG(m == DOTSOCP_METHOD_ACCADMM || m == DOTSOCP_METHOD_PALM, "unknown method");
     DS_ARG(prob.dim == 2, "the reference has PALM and acc-ADMM loops for 2-D problems only");
-    DS_ARG(!multi(), "PALM / acc-ADMM run on one slab");
+    DS_ARG(!(multi() && m == DOTSOCP_METHOD_ACCADMM), "acc-ADMM runs on one slab");
     DS_ARG(!(m == DOTSOCP_METHOD_PALM && prob.weighted), "the reference has no weighted PALM loop");
     method = m;
     int rc = begin(o);

@@ -27,10 +27,20 @@ int Solver::palm_begin() {
         return DOTSOCP_EINVAL;
     }
     // :136-138  tmp_q = A phi; z = BF tmp_q + d (boundary slots keep their uploaded values, like mexBFd)
-    for (auto &s : slabs) {
-        DS_CHECK(launch_grad(s.g, lc, s.phi, s.q2, stream));
-        DS_CHECK(launch_bfd(s.g, s.z, s.q2, lc.s, lc.dF, stream));
+    if (multi()) {     // the forward time difference of a slab's last cell layer reads the right neighbour's first phi layer
+        prof_begin(PH_COMM);
+        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
+        prof_end(PH_COMM);
     }
+    for (auto &s : slabs) DS_CHECK(launch_grad(s.g, lc, s.phi, s.q2, stream));
+    if (multi()) {     // ... and BF of that layer the neighbour's first bx / by layers of tmp_q
+        prof_begin(PH_COMM);
+        DS_CHECK(group_begin());
+        DS_CHECK(shift_edge_halo([](Slab &s) { return s.q2; }));
+        DS_CHECK(group_end());
+        prof_end(PH_COMM);
+    }
+    for (auto &s : slabs) DS_CHECK(launch_bfd(s.g, s.z, s.q2, lc.s, lc.dF, stream));
     deferred = false;
     z_valid = true;
     return 0;
@@ -64,9 +74,24 @@ int Solver::palm_step(bool *brk) {
             DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, stream));
         }
     }
+    DS_CHECK(phase_z_tails());            // time slabs: adjoint tails -> right (the phi head travelled in the last iteration)
     for (auto &s : slabs)
-        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, stream));
+        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, stream,
+                                         s.tail_bx, s.tail_by));
     prof_end(PH_QSTEP0);
+    if (multi()) {
+        // q~ halo -> left (projection of the last cell layer), u0 = q~0 - alpha0 of the last cell -> right (first rhs layer)
+        prof_begin(PH_COMM);
+        for (auto &s : slabs)
+            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q_old, s.alpha, nullptr, s.send_plane, stream));
+        DS_CHECK(group_begin());
+        DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
+        DS_CHECK(group_end());
+        for (auto &s : slabs)
+            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, stream));
+        prof_end(PH_COMM);
+    }
     // ---- step phi :202-205 (its right-hand side was formed by the q-step above) ----
     prof_begin(PH_POISSON);
     DS_CHECK(poisson_all());
@@ -83,11 +108,14 @@ int Solver::palm_step(bool *brk) {
     prof_end(PH_FUSED_A);
     z_valid = false;
     z_prev_ok = false;
+    DS_CHECK(phase_z_tails());            // time slabs: phi^{k+1} head -> left, adjoint tails -> right
     // ---- second q-step + alpha :213-218,221,225 ----
     prof_begin(PH_QSTEP);
     for (auto &s : slabs)
-        DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, nullptr, nullptr, s.q, s.alpha, stream));
+        DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, s.tail_bx, s.tail_by, s.q, s.alpha,
+                                    stream));
     prof_end(PH_QSTEP);
+    DS_CHECK(exchange_q_halo(false));     // time slabs: q^{k+1} halo (multiplier step, KKT block)
     deferred = true;                       // beta^{k+1}: :222-226, executed by the next pass over beta
     const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                 // :231
     const bool timed_out = elapsed() > time_limit;

@@ -532,9 +532,9 @@ int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, do
 // plus the rhs of the phi-step that follows it (:204), A'(q_out - alpha) + c
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                             const double *sx, const double *sy, const double *cvec, double *q_out, const double *alpha,
-                            double *rhs, hipStream_t st) {
+                            double *rhs, hipStream_t st, const double *tail_bx, const double *tail_by) {
     QRhsArgs a{};
-    a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.cvec = cvec;
+    a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.cvec = cvec; a.tail_bx = tail_bx; a.tail_by = tail_by;
     a.alpha_in = alpha; a.q_out = q_out; a.rhs = rhs;
     return launch_qstep_rhs_var(3, g, c, fg, a, st);
 }

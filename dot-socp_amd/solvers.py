@@ -205,9 +205,10 @@ def solver_wsocp_inPALM(var, opts, model, device=0, nslabs=1):
         ctx.close()
 
 
-def solver_socp_PALM(var, opts, model, device=0):
-    """[runHist, sigma] = solver_socp_PALM(var, opts, model)   socp/dot2d/algorithms/solver_socp_PALM.m:1"""
-    ctx = InPALMContext(var, opts, model, weighted=False, device=device, method="PALM")
+def solver_socp_PALM(var, opts, model, device=0, nslabs=1):
+    """[runHist, sigma] = solver_socp_PALM(var, opts, model)   socp/dot2d/algorithms/solver_socp_PALM.m:1
+    nslabs > 1: the time-slab algorithm with all slabs on this one device (as for solver_socp_inPALM)."""
+    ctx = InPALMContext(var, opts, model, weighted=False, device=device, method="PALM", nslabs=nslabs)
     try:
         ctx.run(-1)
         return ctx.finish()

@@ -24,7 +24,7 @@ def _build_fake():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-Wno-unused-result", "-o", FAKE_SO, src])
 
 
-def _worker(rank, world, uid_hex, q, NT):
+def _worker(rank, world, uid_hex, q, NT, method="inPALM"):
     os.environ["DOTSOCP_RCCL_LIB"] = FAKE_SO
     sys.path.insert(0, ROOT)
     try:
@@ -34,9 +34,9 @@ def _worker(rank, world, uid_hex, q, NT):
         rho0, rho1 = get_example_2d("example1", NY, NX)
         t0, t1 = D.capi.slab_range(NT, world, rank)
         var, model = D.initialize_slab(rho0, rho1, NT, t0, t1)
-        o = OD.default_opts(dict(tol=0.0, maxit=K), "inPALM", False)
+        o = OD.default_opts(dict(tol=0.0, maxit=K), method, False)
         D.InitialScaling(var, model, True, None, dim=2)
-        ctx = D.InPALMContext(var, o, model, rccl=(bytes.fromhex(uid_hex), rank, world))
+        ctx = D.InPALMContext(var, o, model, rccl=(bytes.fromhex(uid_hex), rank, world), method=method)
         ctx.run(-1)
         hist, sigma = ctx.finish(download=False)
         ntl = t1 - t0
@@ -57,6 +57,16 @@ def _worker(rank, world, uid_hex, q, NT):
 @pytest.mark.parametrize("world,tsolve,NT", [(2, "tridiag", 16), (2, "dct", 16), (4, "tridiag", 16), (4, "dct", 16),
                                              (2, "tridiag", 32), (2, "dct", 32), (4, "tridiag", 64)])
 def test_one_process_per_slab_matches_single_process(world, tsolve, NT, monkeypatch):
+    _one_process_per_slab(world, tsolve, NT, "inPALM", monkeypatch)
+
+
+@pytest.mark.parametrize("world,NT", [(2, 16), (3, 48)])
+def test_palm_one_process_per_slab(world, NT, monkeypatch):
+    """solver_socp_PALM.m's loop in time-slab mode, one process per slab"""
+    _one_process_per_slab(world, "tridiag", NT, "PALM", monkeypatch)
+
+
+def _one_process_per_slab(world, tsolve, NT, method, monkeypatch):
     monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)        # inherited by the rank processes
     import multiprocessing as mp
     _build_fake()
@@ -67,9 +77,9 @@ def test_one_process_per_slab_matches_single_process(world, tsolve, NT, monkeypa
     # single-process reference
     rho0, rho1 = get_example_2d("example1", NY, NX)
     var, model = D.initialize(rho0, rho1, NT)
-    o = OD.default_opts(dict(tol=0.0, maxit=K), "inPALM", False)
+    o = OD.default_opts(dict(tol=0.0, maxit=K), method, False)
     D.InitialScaling(var, model, True, None, dim=2)
-    hist1, sigma1 = D.solver_socp_inPALM(var, o, model)
+    hist1, sigma1 = (D.solver_socp_PALM if method == "PALM" else D.solver_socp_inPALM)(var, o, model)
     phi1 = var.phi.reshape((NY, NX, NT), order="F")
     beta1 = var.beta.reshape((NY, NX, NT - 1, 10), order="F")
     qi = var.qInd
@@ -81,7 +91,7 @@ def test_one_process_per_slab_matches_single_process(world, tsolve, NT, monkeypa
     uid = D.capi.rccl_unique_id()
     ctx = mp.get_context("spawn")
     qu = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu, NT)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu, NT, method)) for r in range(world)]
     for p in procs:
         p.start()
     results = [qu.get(timeout=300) for _ in procs]

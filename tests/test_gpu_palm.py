@@ -63,6 +63,30 @@ def test_free_running_solve():
     assert hist["method"] == "PALM for DOT-SOCP"
 
 
+@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
+@pytest.mark.parametrize("n,nt", [(32, 16), (33, 49)])
+@pytest.mark.parametrize("nslabs", [2, 3, 4])
+def test_time_slabs_match_single_slab(n, nt, nslabs, tsolve, monkeypatch):
+    """PALM in time-slab mode (all slabs on the one GPU of the test box): four neighbour exchanges per iteration
+    (adjoint tails before each q-step, q~ halo + u0 tail after the first, q halo after the second) around the
+    shared Poisson solve; 40 iterations incl. KKT blocks, sigma updates and the rescale blocks."""
+    monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)
+    rho0, rho1 = get_example_2d("example1", n, n)
+    res = []
+    for ns in (1, nslabs):
+        var, model = D.initialize(rho0, rho1, nt)
+        oo = OD.default_opts(dict(tol=0.0, maxit=40), "PALM", False)
+        D.InitialScaling(var, model, oo["scaling"], None, dim=2)
+        hist, sigma = D.solver_socp_PALM(var, oo, model, nslabs=ns)
+        res.append((var, hist, sigma))
+    (ref, h1, s1), (got, hn, sn) = res
+    np.testing.assert_array_equal(hn["iter"], h1["iter"])
+    np.testing.assert_allclose(hn["kkt"], h1["kkt"], rtol=1e-7, atol=1e-10)
+    assert abs(sn - s1) <= 1e-12 * s1
+    errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-10, errs
+
+
 def test_rejected_configurations():
     from oracle.examples import get_example_1d
     rho0, rho1 = get_example_1d("gaussian", 64)
