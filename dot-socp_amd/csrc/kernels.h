@@ -129,7 +129,8 @@ i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TC = nullptr);
 int launch_qstep_rhs_acc(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi,
                          const double *q2, const double *sx, const double *sy, const double *weight, const double *cvec,
                          double *q_raw, const double *alpha_in, double *alpha_out, double *rhs, double *q_state,
-                         const double *q_anchor, const double *alpha_anchor, const AccCoef &k, hipStream_t st);
+                         const double *q_anchor, const double *alpha_anchor, const AccCoef &k, hipStream_t st,
+                         const double *tail_bx = nullptr, const double *tail_by = nullptr, double *u0_tail = nullptr);
 int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, double *rhs, hipStream_t st);
 // PALM (solver_socp_PALM.m:196-200,137): first q-step without the alpha update; tmp_q = A phi in q layout
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,

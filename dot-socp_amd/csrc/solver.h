@@ -145,6 +145,7 @@ struct Solver {
     int phase_phi();
     int phase_z(hipStream_t st, int part = 0);   // part 0: all chunks; 1: all but the last chunk; 2: the last chunk
     int phase_z_tails();
+    int ship_tails();        // time slabs: finalise + send the adjoint tails (-> right) and the phi head (-> left)
     int phase_q(int part = 0);   // part 0: whole q-step; 1: the middle chunks on stream_z; 2: first + last chunk, then finish
     int phase_mult();
     int materialise();

@@ -685,7 +685,6 @@ int Solver::begin_method(const dotsocp_opts *o, int m, const dotsocp_acc_opts *a
     if (m == DOTSOCP_METHOD_INPALM) return begin(o);
     DS_ARG(m == DOTSOCP_METHOD_ACCADMM || m == DOTSOCP_METHOD_PALM, "unknown method");
     DS_ARG(prob.dim == 2, "the reference has PALM and acc-ADMM loops for 2-D problems only");
-    DS_ARG(!(multi() && m == DOTSOCP_METHOD_ACCADMM), "acc-ADMM runs on one slab");
     DS_ARG(!(m == DOTSOCP_METHOD_PALM && prob.weighted), "the reference has no weighted PALM loop");
     method = m;
     int rc = begin(o);
@@ -848,7 +847,11 @@ int Solver::phase_z(hipStream_t st, int part) {
 
 // time-slab mode: ship the adjoint sums of every slab's last cell to its right neighbour (main stream)
 int Solver::phase_z_tails() {
-    if (fused && multi()) {
+    return fused ? ship_tails() : 0;
+}
+
+int Solver::ship_tails() {
+    if (multi()) {
         // adjoint sums of every slab's last cell for the first edge layer of its right neighbour
         prof_begin(PH_COMM);
         for (auto &s : slabs)

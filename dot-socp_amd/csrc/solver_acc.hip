@@ -106,6 +106,14 @@ int Solver::acc_rescale_block() {
     double normPhis = 0, normAlps = 0;
     auto norms = [&](double &nPhis, double &nAlps) -> int {
         double S[S_COUNT + 1];
+        if (multi()) {
+            // the sums are taken at the extrapolated state, whose phi / q halos nobody maintains (the q-step folds the
+            // extrapolation of q over owned entries only, phi is extrapolated over owned nodes)
+            prof_begin(PH_COMM);
+            DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
+            prof_end(PH_COMM);
+            DS_CHECK(exchange_q_halo(false));
+        }
         DS_CHECK(kkt_sums(S));
         const double sh = sqrt(h);
         const double normPhi = sh * sqrt(S[S_PHI2]), normQ = sh * sqrt(S[S_Q2]), normZ = sh * sqrt(S[S_Z2]);
@@ -162,7 +170,8 @@ int Solver::acc_step(bool *brk) {
     it += 1;
     DS_CHECK(acc_rescale_block());
     const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                   // :253
-    const bool timed_out = elapsed() > time_limit;
+    // one slab per process: time-outs are detected at KKT checks only, from the agreed clock (see Solver::kkt_block)
+    const bool timed_out = remote() ? false : (elapsed() > time_limit);
     // the time-limit term of :254 is evaluated before the q-step here (the device queue is asynchronous)
     const bool kkt_due = opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out;
     const AccCoef kc = acc_coef();
@@ -179,20 +188,35 @@ int Solver::acc_step(bool *brk) {
         }
         prof_end(PH_ACC_GATHER);
     }
+    // time slabs: adjoint tails of (z + beta) -> right, head of the extrapolated phi -> left
+    DS_CHECK(ship_tails());
     // q^+ (raw, for the cone pass and the KKT block) always goes to q_old and the right-hand side of the phi-step
     // to w0; without a KKT check the Halpern step of q (in place) and alpha (ping-pong) is part of the same pass
     prof_begin(PH_QSTEP);
     for (auto &s : slabs) {
         if (fold) {
             DS_CHECK(launch_qstep_rhs_acc(2, s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.c, s.q_old, s.alpha,
-                                          s.alpha2, s.w0, s.q, s.q_a, s.alpha_a, kc, stream));
+                                          s.alpha2, s.w0, s.q, s.q_a, s.alpha_a, kc, stream, s.tail_bx, s.tail_by,
+                                          s.g.last ? nullptr : s.send_plane));
             std::swap(s.alpha, s.alpha2);
         } else {
             DS_CHECK(launch_qstep_rhs_acc(1, s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.c, s.q_old, s.alpha,
-                                          s.alpha_p, s.w0, nullptr, nullptr, nullptr, kc, stream));
+                                          s.alpha_p, s.w0, nullptr, nullptr, nullptr, kc, stream, s.tail_bx, s.tail_by,
+                                          s.g.last ? nullptr : s.send_plane));
         }
     }
     prof_end(PH_QSTEP);
+    if (multi()) {
+        // raw q^+ halo -> left (cone pass of the last cell layer, KKT block), raw u0 tail -> right (first rhs layer)
+        prof_begin(PH_COMM);
+        DS_CHECK(group_begin());
+        DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
+        DS_CHECK(group_end());
+        for (auto &s : slabs)
+            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, stream));
+        prof_end(PH_COMM);
+    }
 
     // ---- multipliers + step z (:234-239,246-249); the cone pass does not need phi^+ ----
     prof_begin(PH_ACC_CONE);
@@ -220,6 +244,11 @@ int Solver::acc_step(bool *brk) {
 
     // ---- KKT (:251-367) at x^+ ----
     if (kkt_due) {
+        if (multi()) {     // A phi^+ of a slab's last cell layer reads the right neighbour's first phi^+ layer
+            prof_begin(PH_COMM);
+            DS_CHECK(shift(-1, [](Slab &s) { return s.phi_p; }, [](Slab &s) { return s.phi_p + s.g.plane * s.g.ntl; }, ny * nx));
+            prof_end(PH_COMM);
+        }
         acc_swap_state();
         DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
         if (*brk) return 0;                                // :322-325: the outputs are x^+ (pointers stay swapped)

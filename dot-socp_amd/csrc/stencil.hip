@@ -316,6 +316,7 @@ __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double 
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
+    double *u0_tail;   // time slabs (optional): raw u0 = w.*q0^+ - alpha0^+ of the last owned cell layer, for the right slab's rhs
     i64 TC, z0;        // layers per chunk, first chunk of this launch
     // VAR 2 (acc-ADMM, Halpern step folded in): q_out receives the raw q^+ (the cone pass needs it), the
     // extrapolated q goes to q_state in place and the extrapolated alpha to alpha_out
@@ -390,6 +391,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 tmp += c.at * pT;
                 const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
                 put(node, qn, an, ain);
+                if (a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
             }
             if (x < g.nx - 1) {
                 const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
@@ -461,9 +463,11 @@ int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, cons
 int launch_qstep_rhs_acc(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi,
                          const double *q2, const double *sx, const double *sy, const double *weight, const double *cvec,
                          double *q_raw, const double *alpha_in, double *alpha_out, double *rhs, double *q_state,
-                         const double *q_anchor, const double *alpha_anchor, const AccCoef &k, hipStream_t st) {
+                         const double *q_anchor, const double *alpha_anchor, const AccCoef &k, hipStream_t st,
+                         const double *tail_bx, const double *tail_by, double *u0_tail) {
     QRhsArgs a{};
     a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.weight = weight; a.cvec = cvec;
+    a.tail_bx = tail_bx; a.tail_by = tail_by; a.u0_tail = u0_tail;
     a.alpha_in = alpha_in; a.q_out = q_raw; a.alpha_out = alpha_out; a.rhs = rhs;
     a.q_state = q_state; a.q_anchor = q_anchor; a.alpha_anchor = alpha_anchor;
     a.c1 = k.c1; a.c2 = k.c2; a.om_rho = k.om_rho; a.rho = k.rho;

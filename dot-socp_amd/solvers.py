@@ -216,10 +216,10 @@ def solver_socp_PALM(var, opts, model, device=0, nslabs=1):
         ctx.close()
 
 
-def solver_socp_accADMM(var, opts, model, device=0):
+def solver_socp_accADMM(var, opts, model, device=0, nslabs=1):
     """[runHist, sigma] = solver_socp_accADMM(var, opts, model)   socp/dot2d/algorithms/solver_socp_accADMM.m:1
     opts: sigma, maxit, tol, ifCheckStepByStep (+ restart, rho, theta, checkPrimDualFeas, time_limit, scaling)."""
-    ctx = InPALMContext(var, opts, model, weighted=False, device=device, method="acc-ADMM")
+    ctx = InPALMContext(var, opts, model, weighted=False, device=device, method="acc-ADMM", nslabs=nslabs)
     try:
         ctx.run(-1)
         return ctx.finish()
@@ -227,9 +227,9 @@ def solver_socp_accADMM(var, opts, model, device=0):
         ctx.close()
 
 
-def solver_wsocp_accADMM(var, opts, model, device=0):
+def solver_wsocp_accADMM(var, opts, model, device=0, nslabs=1):
     """socp/wdot2d/algorithms/solver_wsocp_accADMM.m:1"""
-    ctx = InPALMContext(var, opts, model, weighted=True, device=device, method="acc-ADMM")
+    ctx = InPALMContext(var, opts, model, weighted=True, device=device, method="acc-ADMM", nslabs=nslabs)
     try:
         ctx.run(-1)
         return ctx.finish()

@@ -197,7 +197,7 @@ int dotsocp_begin(dotsocp_ctx *ctx, const dotsocp_opts *opts);
 /* Same as dotsocp_begin for another loop file of the reference: DOTSOCP_METHOD_*; `acc` may be NULL
  * (reference defaults) and is read for DOTSOCP_METHOD_ACCADMM only.  run / finish / downloads are
  * unchanged; result.times follows the inPALM order with the variant's extra column in time_extra.
- * acc-ADMM runs on one slab (no time-slab mode yet: DOTSOCP_EINVAL otherwise); inPALM and PALM run on time slabs. */
+ * All three loops run on time slabs (nslabs > 1 or dotsocp_attach_rccl). */
 int dotsocp_begin_method(dotsocp_ctx *ctx, const dotsocp_opts *opts, int method, const dotsocp_acc_opts *acc);
 int dotsocp_run(dotsocp_ctx *ctx, dotsocp_i64 n_iters, dotsocp_i64 *done);
 int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res);

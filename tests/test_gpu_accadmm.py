@@ -94,10 +94,40 @@ def test_free_running_solve():
     assert hist["method"] == "acc-ADMM for DOT-SOCP"
 
 
-def test_rejected_configurations():
-    rho0, rho1 = get_example_2d("example1", 16, 16)
-    var, model = D.initialize(rho0, rho1, 8)
-    D.InitialScaling(var, model, True, None, dim=2)
-    o = OD.default_opts(dict(tol=1e-3), "acc-ADMM")
-    with pytest.raises(D.capi.DotsocpError):
-        D.InPALMContext(var, o, model, nslabs=2, method="acc-ADMM")
+@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
+@pytest.mark.parametrize("case", ["halpern_32x16", "halpern_33x49", "theta3_32x16", "weighted_32x48", "checkstep_24x12"])
+@pytest.mark.parametrize("nslabs", [2, 3, 4])
+def test_time_slabs_match_single_slab(case, nslabs, tsolve, monkeypatch):
+    """acc-ADMM in time-slab mode (all slabs on the one GPU of the test box): adjoint tails + phi head in front of the
+    q-step, raw q^+ halo + u0 tail behind it, phi^+ head in front of a KKT block; folded (Halpern, no KKT check) and
+    unfolded iterations, sigma updates, rescale blocks and restarts included."""
+    monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)
+    kind, dims = case.split("_")
+    n, nt = [int(v) for v in dims.split("x")]
+    rho0, rho1 = get_example_2d("example1", n, n)
+    weight = None
+    opts = dict(tol=0.0, maxit=90)
+    if kind == "theta3":
+        opts["theta"] = 3.0
+    if kind == "checkstep":
+        opts.update(ifCheckStepByStep=True, maxit=25)
+    if kind == "weighted":
+        barrier = gene_barrier_of_circle_pillar()
+        weight = get_weight_by_barrier(n, n, nt, barrier)
+        rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    res = []
+    for ns in (1, nslabs):
+        var, model = D.initialize(rho0, rho1, nt)
+        if weight is not None:
+            model.weight = np.asarray(weight, dtype=np.float64)
+        oo = OD.default_opts(opts, "acc-ADMM", weight is not None)
+        D.InitialScaling(var, model, oo["scaling"], None, dim=2, weighted=weight is not None)
+        solve = D.solver_wsocp_accADMM if weight is not None else D.solver_socp_accADMM
+        hist, sigma = solve(var, oo, model, nslabs=ns)
+        res.append((var, hist, sigma))
+    (ref, h1, s1), (got, hn, sn) = res
+    np.testing.assert_array_equal(hn["iter"], h1["iter"])
+    np.testing.assert_allclose(hn["kkt"], h1["kkt"], rtol=1e-7, atol=1e-10)
+    assert abs(sn - s1) <= 1e-12 * s1
+    errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
+    assert max(errs.values()) <= (1e-8 if weight is not None else 1e-10), errs

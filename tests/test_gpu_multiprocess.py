@@ -66,6 +66,12 @@ def test_palm_one_process_per_slab(world, NT, monkeypatch):
     _one_process_per_slab(world, "tridiag", NT, "PALM", monkeypatch)
 
 
+@pytest.mark.parametrize("world,NT", [(2, 16), (3, 48)])
+def test_accadmm_one_process_per_slab(world, NT, monkeypatch):
+    """solver_socp_accADMM.m's loop in time-slab mode, one process per slab"""
+    _one_process_per_slab(world, "tridiag", NT, "acc-ADMM", monkeypatch)
+
+
 def _one_process_per_slab(world, tsolve, NT, method, monkeypatch):
     monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)        # inherited by the rank processes
     import multiprocessing as mp
@@ -79,7 +85,8 @@ def _one_process_per_slab(world, tsolve, NT, method, monkeypatch):
     var, model = D.initialize(rho0, rho1, NT)
     o = OD.default_opts(dict(tol=0.0, maxit=K), method, False)
     D.InitialScaling(var, model, True, None, dim=2)
-    hist1, sigma1 = (D.solver_socp_PALM if method == "PALM" else D.solver_socp_inPALM)(var, o, model)
+    solve1 = {"PALM": D.solver_socp_PALM, "acc-ADMM": D.solver_socp_accADMM}.get(method, D.solver_socp_inPALM)
+    hist1, sigma1 = solve1(var, o, model)
     phi1 = var.phi.reshape((NY, NX, NT), order="F")
     beta1 = var.beta.reshape((NY, NX, NT - 1, 10), order="F")
     qi = var.qInd
