@@ -316,7 +316,7 @@ __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double 
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
-    double *u0_tail;   // time slabs (optional): raw u0 = w.*q0^+ - alpha0^+ of the last owned cell layer, for the right slab's rhs
+    double *u0_tail;   // time slabs, VAR 1 / 2 (optional): raw u0 = w.*q0^+ - alpha0^+ of the last owned cell layer, for the right slab's rhs
     i64 TC, z0;        // layers per chunk, first chunk of this launch
     // VAR 2 (acc-ADMM, Halpern step folded in): q_out receives the raw q^+ (the cone pass needs it), the
     // extrapolated q goes to q_state in place and the extrapolated alpha to alpha_out
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 tmp += c.at * pT;
                 const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
                 put(node, qn, an, ain);
-                if (a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
+                if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
             }
             if (x < g.nx - 1) {
                 const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
