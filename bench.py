@@ -254,6 +254,11 @@ def main():
                      "avg_launch_ms": proj_ms, "launches": proj_n},
         "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
     }
+    if world > 1 or args.nslabs > 1:
+        # time-slab mode: the timed interval covers both chunk launches of the slab's cone pass on the second stream --
+        # they share HBM with the Poisson solve on the main stream and wait for the q halo in between; the N = 1 line
+        # is the kernel's roofline figure
+        out["roofline"]["note"] = "interval spans two chunk launches overlapped with the phi-step and the halo wait"
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.method == "inPALM":
             out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
