@@ -120,8 +120,8 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
-                     double *rhs, hipStream_t st, i64 z0 = 0, i64 zcount = -1);
-// chunks of time layers of that launch ([z0, z0 + zcount) selects a range; chunks are independent of each other: only
+                     double *rhs, hipStream_t st, i64 z0 = 0, i64 zcount = -1, i64 zstride = 1);
+// chunks of time layers of that launch (z0 + i * zstride, i < zcount, selects chunks; chunks are independent of each other: only
 // chunk 0 reads the adjoint tails of the left neighbour slab and only the last one the phi halo of the right one)
 i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TC = nullptr);
 // acc-ADMM: q-step + multiplier + next rhs (var 1: raw q^+, alpha^+; var 2: raw q^+ plus the Halpern step of q in

@@ -878,14 +878,11 @@ int Solver::phase_q(int part) {
             if (qrhs) {
                 // ... and the right-hand side of the next phi-step is formed in the same pass (alpha ping-pongs)
                 const i64 C = qstep_rhs_chunks(s.g, s.fg);
-                for (int leg = 0; leg < 2; ++leg) {
-                    i64 z0 = 0, zc = C;
-                    if (part == 1) { z0 = 1; zc = C - 2; if (leg) break; }
-                    else if (part == 2) { z0 = leg ? C - 1 : 0; zc = 1; }
-                    else if (leg) break;
-                    DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.c,
-                                              s.q_old, s.alpha, s.alpha2, s.w0, st, z0, zc));
-                }
+                i64 z0 = 0, zc = C, zs = 1;
+                if (part == 1) { z0 = 1; zc = C - 2; }             // the chunks in the middle
+                else if (part == 2) { zc = 2; zs = C - 1; }        // first and last chunk in one launch
+                DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.c,
+                                          s.q_old, s.alpha, s.alpha2, s.w0, st, z0, zc, zs));
                 if (part != 1) std::swap(s.alpha, s.alpha2);
             } else {
                 DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by,

@@ -317,7 +317,7 @@ struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
     double *u0_tail;   // time slabs, VAR 1 / 2 (optional): raw u0 = w.*q0^+ - alpha0^+ of the last owned cell layer, for the right slab's rhs
-    i64 TC, z0;        // layers per chunk, first chunk of this launch
+    i64 TC, z0, zstride;   // layers per chunk; this launch runs the chunks z0 + blockIdx.z * zstride
     // VAR 2 (acc-ADMM, Halpern step folded in): q_out receives the raw q^+ (the cone pass needs it), the
     // extrapolated q goes to q_state in place and the extrapolated alpha to alpha_out
     double *q_state;
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     const i64 y = (i64)blockIdx.x * TILE_Y + lane;
     const i64 x = (i64)blockIdx.y * TILE_X + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
-    const i64 t0 = ((i64)blockIdx.z + a.z0) * a.TC;
+    const i64 t0 = ((i64)blockIdx.z * a.zstride + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ntl) ? t0 + a.TC : g.ntl;
     auto bx_q2 = [&](i64 yy, i64 xx, i64 tl, i64 e) {
         double q2 = a.q2v[e];
@@ -447,16 +447,16 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
 }
 
 static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st,
-                                i64 z0 = 0, i64 zcount = -1);
+                                i64 z0 = 0, i64 zcount = -1, i64 zstride = 1);
 
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
-                     double *rhs, hipStream_t st, i64 z0, i64 zcount) {
+                     double *rhs, hipStream_t st, i64 z0, i64 zcount, i64 zstride) {
     QRhsArgs a{};
     a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.weight = weight; a.tail_bx = tail_bx; a.tail_by = tail_by;
     a.cvec = cvec; a.alpha_in = alpha_in; a.q_out = q_out; a.alpha_out = alpha_out; a.rhs = rhs;
-    return launch_qstep_rhs_var(0, g, c, fg, a, st, z0, zcount);
+    return launch_qstep_rhs_var(0, g, c, fg, a, st, z0, zcount, zstride);
 }
 
 // var 1 / 2: the acc-ADMM flavours (see k_qstep_rhs); `acc` carries the Halpern weights and the extra arrays of var 2
@@ -495,13 +495,14 @@ i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TCout) {
 }
 
 static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const FusedGeom &fg, QRhsArgs a, hipStream_t st,
-                                i64 z0, i64 zcount) {
+                                i64 z0, i64 zcount, i64 zstride) {
     i64 TC = 1;
     const i64 chunks = qstep_rhs_chunks(g, fg, &TC);
     if (zcount < 0) zcount = chunks - z0;
-    if (z0 < 0 || zcount <= 0 || z0 + zcount > chunks) return 0;
+    if (z0 < 0 || zcount <= 0 || zstride < 1 || z0 + (zcount - 1) * zstride >= chunks) return 0;
     a.TC = TC;
     a.z0 = z0;
+    a.zstride = zstride;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(TILE_Y, TILE_X);
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
