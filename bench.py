@@ -10,7 +10,9 @@ levelN = 1, method "inPALM" (tau = 1.9, sigma0 = 1, scaling on), tol = 0 so that
 exactly W + K iterations.  Inputs are resident in HBM before the timed region starts.
 
 N = 1: dot2d 1024 x 1024 x 128 (BASELINE.json configs[2]).  N > 1: the same grid split into N time
-slabs, one process per GPU (strong scaling).  Rank 0 prints ONE JSON line; besides the contract
+slabs, one process per GPU (strong scaling); `--grid 2048 2048 256 --gpus 8` is BASELINE.json configs[3].
+N > 1 runs either under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` or plainly
+as `python bench.py --gpus N ...`, which starts the N ranks itself (self_launch).  Rank 0 prints ONE JSON line; besides the contract
 fields it carries `roofline` (cone-projection kernel, HIP-event timing on the launch stream) and
 `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
 """
@@ -114,14 +116,71 @@ def cpu_baseline(workload, ny, nx, nt, budget_s):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an outer launcher: start the N ranks as fresh child processes (this
+    process has neither imported torch nor touched HIP, and it never execs), relay rank 0's JSON line and exit
+    with the worst child's return code.  Under `python -m torch.distributed.run` WORLD_SIZE is already set and
+    this function is not reached."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    limit = float(os.environ.get("DOTSOCP_BENCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + limit
+    out0, worst, got0 = "", 0, False
+    while True:
+        if not got0:
+            try:
+                out0, _ = procs[0].communicate(timeout=2.0)
+                got0 = True
+            except subprocess.TimeoutExpired:
+                pass
+        else:
+            time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):      # a rank died: give the others a moment, then stop them
+            time.sleep(5.0)
+            worst = 1
+            break
+        if time.time() > deadline:
+            worst = 124
+            break
+    for p in procs:                       # exact PIDs of the children started above, nothing else
+        if p.poll() is None:
+            p.send_signal(signal.SIGKILL)
+            p.wait()
+            worst = worst or 124
+        elif p.returncode != 0:
+            worst = worst or (p.returncode if p.returncode > 0 else 1)
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if worst == 0 and len(lines) != 1:
+        worst = 1
+    if worst == 0:
+        print(lines[0], flush=True)
+    else:
+        sys.stderr.write(f"bench.py: {n}-rank run failed (rc {worst}); rank 0 stdout tail:\n{out0[-2000:]}\n")
+    raise SystemExit(worst)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     import torch
     import dotsocp_amd as D

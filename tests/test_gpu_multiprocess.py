@@ -157,3 +157,23 @@ def test_bench_under_torchrun_rehearsal(world):
     assert rec["config"]["kkt_checks_in_timed_region"] == ref["config"]["kkt_checks_in_timed_region"]
     assert np.isfinite(rec["value"]) and rec["value"] > 0
     assert rec["roofline"]["launches"] > 0 and rec["kernel_ms"]["comm"] > 0
+
+
+@pytest.mark.parametrize("world", [2])
+def test_bench_self_launch_rehearsal(world):
+    """`python bench.py --gpus N` with NO outer launcher: bench.py starts its own rank processes (self_launch),
+    relays rank 0's single JSON line and returns 0.  Ranks share the test box's GPU (gloo + the stand-in)."""
+    import json
+    _build_fake()
+    env = dict(os.environ, DOTSOCP_RCCL_LIB=FAKE_SO, DOTSOCP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "12", "--warmup", "3",
+           "--no-cpu-baseline", "--grid", "64", "48", "16"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == world and rec["steps"] == 12 and rec["config"]["grid"] == [64, 48, 16]
+    assert np.isfinite(rec["value"]) and rec["value"] > 0
