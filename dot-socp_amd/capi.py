@@ -66,10 +66,12 @@ SYMBOLS = {
     "dotsocp_bfd_dev": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl, dbl, vp]),
     "dotsocp_bfd_conj_dev": (ctypes.c_int, [vp, vp, i64, i64, i64, dbl, vp]),
     "dotsocp_create": (vp, [ctypes.POINTER(Problem), ctypes.c_int, ctypes.c_int]),
+    "dotsocp_create_multi": (vp, [ctypes.POINTER(Problem), ctypes.c_int, ctypes.c_int]),
     "dotsocp_destroy": (None, [vp]),
     "dotsocp_rccl_unique_id": (ctypes.c_int, [vp]),
     "dotsocp_attach_rccl": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int]),
     "dotsocp_slab_range": (ctypes.c_int, [i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
+    "dotsocp_field_len": (i64, [ctypes.POINTER(Problem), ctypes.c_int]),
     "dotsocp_upload": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "dotsocp_download": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "dotsocp_begin": (ctypes.c_int, [vp, ctypes.POINTER(Opts)]),

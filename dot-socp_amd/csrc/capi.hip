@@ -245,6 +245,16 @@ dotsocp_ctx *dotsocp_create(const dotsocp_problem *prob, int device, int nslabs)
     return c;
 }
 
+dotsocp_ctx *dotsocp_create_multi(const dotsocp_problem *prob, int first_device, int ngpu) {
+    dotsocp_ctx *c = new (std::nothrow) dotsocp_ctx();
+    if (!c) { set_error("out of host memory"); return nullptr; }
+    if (c->s.init(prob, first_device, ngpu, true) != 0) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
 void dotsocp_destroy(dotsocp_ctx *ctx) { delete ctx; }
 
 int dotsocp_slab_range(dotsocp_i64 nt, int world, int rank, dotsocp_i64 *t0, dotsocp_i64 *t1) {
@@ -273,6 +283,19 @@ int dotsocp_attach_rccl(dotsocp_ctx *ctx, const unsigned char id[128], int rank,
         if (!ctx) { set_error("ctx is NULL"); return DOTSOCP_EINVAL; } \
         (void)hipGetLastError();   /* a stale error of an earlier, failed call must not be blamed on this one */ \
     } while (0)
+
+dotsocp_i64 dotsocp_field_len(const dotsocp_problem *p, int field) {
+    if (!p || (p->dim != 1 && p->dim != 2) || p->nt < 2 || p->nx < 1 || (p->dim == 2 && p->ny < 1)) return -1;
+    const i64 ny = p->dim == 1 ? p->nx : p->ny, nx = p->dim == 1 ? 1 : p->nx, nt = p->nt;
+    const i64 Nphi = ny * nx * nt, Nz = ny * nx * (nt - 1);
+    const i64 Nq = Nz + ny * (nx - 1) * nt + (ny - 1) * nx * nt;
+    switch (field) {
+        case DOTSOCP_F_PHI: case DOTSOCP_F_C: return Nphi;
+        case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: return Nq;
+        case DOTSOCP_F_Z: case DOTSOCP_F_BETA: return Nz * (p->dim == 1 ? 6 : 10);
+        default: return -1;
+    }
+}
 
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host) { CTX_OR_FAIL(); return ctx->s.upload(field, host); }
 int dotsocp_download(dotsocp_ctx *ctx, int field, double *host) { CTX_OR_FAIL(); return ctx->s.download(field, host); }
@@ -335,9 +358,8 @@ int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dots
 
 int dotsocp_synchronize(dotsocp_ctx *ctx) {
     CTX_OR_FAIL();
-    DS_HIP(hipSetDevice(ctx->s.device));
-    DS_HIP(hipStreamSynchronize(ctx->s.stream));
-    return 0;
+    ctx->s.cur_dev = -1;
+    return ctx->s.sync_all();
 }
 
 }  // extern "C"

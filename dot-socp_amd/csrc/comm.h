@@ -24,6 +24,19 @@ struct Rccl {
 
 Rccl &rccl_api();
 
+// Solver members only: a failing Send / Recv inside open groups closes every open group (Solver::open_groups counts
+// GroupStart minus GroupEnd) before the error is returned, so the communicator is not left with a dangling group
+#define DS_NCCL_G(call)                                                                        \
+    do {                                                                                       \
+        ncclResult_t r__ = (call);                                                             \
+        if (r__ != ncclSuccess) {                                                              \
+            dotsocp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,                   \
+                               dotsocp::rccl_api().GetErrorString(r__));                       \
+            for (; open_groups > 0; --open_groups) (void)dotsocp::rccl_api().GroupEnd();       \
+            return DOTSOCP_ECOMM;                                                              \
+        }                                                                                      \
+    } while (0)
+
 #define DS_NCCL(call)                                                                          \
     do {                                                                                       \
         ncclResult_t r__ = (call);                                                             \

@@ -106,8 +106,13 @@ int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, doubl
 int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, double *betaf, double *neg, double sc_in0,
                         double sc_in1, double sc_out, hipStream_t st);
 int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t st);
+// slab-aware: `out` holds the slab's own layers (ntl node layers resp. ncl cell layers); a_prev: launch_out_tail of the
+// left neighbour (nullptr on the first slab)
 int launch_outputs(const Grid &g, const double *q, const double *alpha, const double *weight, const double *rho0,
-                   const double *rho1, double sig, double cD, double dD, int which, double *out, hipStream_t st);
+                   const double *rho1, const double *a_prev, double sig, double cD, double dD, int which, double *out,
+                   hipStream_t st);
+int launch_out_tail(const Grid &g, const double *alpha, const double *weight, double sig, double cD, double *out,
+                    hipStream_t st);
 
 // ---------------- stencil.hip ----------------
 // q-step + alpha update reading the precomputed adjoint sums q2 (+ side buffers) of the fused kernel;

@@ -27,11 +27,28 @@ inline void dfree(void *p) {
     if (p) (void)hipFree(p);
 }
 
+// Resources that live once per HIP device and are shared by the slabs placed on it.
+struct DevRes {
+    int dev = 0;
+    DctPlan *py = nullptr, *px = nullptr, *pt = nullptr;
+    double *cy = nullptr, *cx = nullptr, *ct = nullptr;   // DCT eigenvalue tables
+};
+
 // One time slab (common.h: Grid).  Single-GPU runs have exactly one; `nslabs` > 1 keeps several in
-// one process (the multi-GPU algorithm with device-to-device copies as "communication"); with an
-// RCCL communicator attached the process holds the single slab `rank` of `world`.
+// one process -- every slab with its own device (dotsocp_create_multi: slab r on device (first + r) mod #devices;
+// dotsocp_create: all on one device), its own pair of streams and peer copies between neighbours as
+// "communication"; with an RCCL communicator attached the process holds the single slab `rank` of `world`.
+#define DS_XEV 8
 struct Slab {
     int index = 0;              // global slab number
+    int dev = 0;                // HIP device this slab lives on
+    hipStream_t st = nullptr;   // main stream of the slab (slab 0: Solver::stream)
+    hipStream_t st_z = nullptr; // second stream: cone pass / middle q-step chunks when they overlap the rest
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_halo = nullptr;
+    hipEvent_t xev[DS_XEV] = {nullptr};   // ordering of cross-slab copies (Solver::xcopy), used round-robin
+    int xev_next = 0;
+    DevRes *res = nullptr;      // plans / tables of `dev`
+    double *h_sums = nullptr;   // pinned host copy of this slab's KKT partial sums [S_COUNT]
     Grid g;
     double *phi = nullptr;      // NphiAlloc (owned nodes + halo layer)
     double *q = nullptr;        // NqAlloc
@@ -63,6 +80,9 @@ struct Slab {
     double *phi_a = nullptr, *q_a = nullptr, *alpha_a = nullptr, *z_a = nullptr, *beta_a = nullptr;
 };
 
+// every slab this process holds, with the slab's device made current first (member functions returning int)
+#define FOR_SLABS(s) for (auto &s : slabs) if (int rc_use__ = use(s)) return rc_use__; else
+
 bool if_adjust_sigma(double iter, double last_iter);   // IfAdjustSigma (solver_socp_inPALM.m:361-379)
 
 enum Phase { PH_RHS = 0, PH_POISSON, PH_PROJ, PH_QSTEP, PH_BETA, PH_KKT, PH_FUSED_A, PH_FUSED_B, PH_MATERIALISE,
@@ -72,17 +92,34 @@ struct Solver {
     dotsocp_problem prob{};
     int device = 0;
     i64 ny = 0, nx = 0, nt = 0;     // internal dims (1-D problems: ny = nx1d, nx = 1)
-    hipStream_t stream = nullptr;      // main stream: everything but the overlapped cone pass; all communication
+    // streams of slab 0 (created by init() on `device`; the other in-process slabs create their own): the main stream
+    // carries everything but the overlapped cone pass, and all RCCL communication
+    hipStream_t stream = nullptr;
     hipStream_t stream_z = nullptr;    // cone pass when it overlaps the phi step
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_halo = nullptr;
+    bool multi_device = false;         // dotsocp_create_multi: slab r on device (device + r) mod #devices
+    int ndev_visible = 1;
+    std::vector<DevRes *> devres;      // one per device in use
+    int cur_dev = -1;                  // device made current by use() (-1: unknown)
+    int use(const Slab &s);            // hipSetDevice(s.dev) unless it already is the current one
+    int use_dev(int d);
+    DevRes *res_for(int dev);          // plans + tables on `dev` (created on first request)
+    // in-process slabs: dst (on `to`) <- src (on `from`), ordered after everything enqueued so far on both slabs'
+    // main streams and before everything enqueued later on either (what one shared stream used to give for free)
+    int xcopy(Slab &from, const double *src, Slab &to, double *dst, i64 count);
+    int xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, double *dst, size_t dpitch, size_t width,
+                size_t height);
+    int sync_all();                    // host waits for every stream of every slab
+    // fork / join of the second stream of every slab
+    int fork_z(bool also_halo_event = false);
+    int join_z();
     bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process
     int world = 1;                  // total number of slabs
     int rank = 0;                   // RCCL mode: this process's slab
     void *nccl = nullptr;           // ncclComm_t when a communicator is attached
-    DctPlan *py = nullptr, *px = nullptr, *pt = nullptr;
-    double *cy = nullptr, *cx = nullptr, *ct = nullptr;   // DCT eigenvalue tables (device)
-    double *h_sums = nullptr;       // pinned host buffer [S_COUNT + 1]
+    int open_groups = 0;            // ncclGroupStart calls not yet matched by ncclGroupEnd (comm.h: DS_NCCL_G)
+    double *h_sums = nullptr;       // pinned host buffer [S_COUNT + 1] (RCCL mode: reduced sums + clock)
     double *d_red = nullptr;        // device buffer for the cross-rank reduction [S_COUNT + 1]
 
     // ---- loop state (mirrors solver_socp_inPALM.m:11-135) ----
@@ -125,7 +162,7 @@ struct Solver {
     i64 phase_launches[PH_COUNT] = {0};
 
     ~Solver();
-    int init(const dotsocp_problem *p, int device, int nslabs);
+    int init(const dotsocp_problem *p, int device, int nslabs, bool multi_dev = false);
     int attach_rccl(const unsigned char *id, int rank, int world);
     int upload(int field, const double *host);
     int download(int field, double *host);
@@ -143,7 +180,8 @@ struct Solver {
     int step(bool *brk);
     int rescale_block();
     int phase_phi();
-    int phase_z(hipStream_t st, int part = 0);   // part 0: all chunks; 1: all but the last chunk; 2: the last chunk
+    // on_z: on every slab's second stream; part 0: all chunks; 1: all but the last chunk; 2: the last chunk
+    int phase_z(bool on_z, int part = 0);
     int phase_z_tails();
     int ship_tails();        // time slabs: finalise + send the adjoint tails (-> right) and the phi head (-> left)
     int phase_q(int part = 0);   // part 0: whole q-step; 1: the middle chunks on stream_z; 2: first + last chunk, then finish
@@ -154,8 +192,9 @@ struct Solver {
     int scale_state(double a_mul, double a_div, double q_div, bool with_c);
     void update_coef();
     double elapsed() const;
-    void prof_begin(int phase, hipStream_t st = nullptr);
-    void prof_end(int phase, hipStream_t st = nullptr);
+    // HIP events on slab 0's main stream (on_z: its second stream); slab 0 stands for all (slabs run in lockstep)
+    void prof_begin(int phase, bool on_z = false);
+    void prof_end(int phase, bool on_z = false);
     int prof_flush();
     int poisson_all();
     int transpose(bool forward);

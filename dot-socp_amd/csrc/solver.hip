@@ -1,12 +1,13 @@
 // Host side of the device-resident inPALM / ALG2 loop.  The scalar control flow (sigma rule,
 // rescale triggers, KKT ratios, stop test) restates socp/dot2d/algorithms/solver_socp_inPALM.m
 // (and solver_wsocp_inPALM.m for the weighted variant) line by line; all array work is done by the
-// kernels of cone.hip / fused.hip / stencil.hip / dct.hip / kkt.hip on one HIP stream.
+// kernels of cone.hip / fused.hip / stencil.hip / dct.hip / kkt.hip on the slab's HIP streams.
 //
 // Time-slab mode (world > 1): the grid is cut along t (common.h: Grid).  Per iteration a slab
 // exchanges six ny x nx layers with its neighbours (u0 tail, phi head, adjoint tails, bx/by heads)
-// and the Poisson solve transposes slabs <-> pencils around its t-axis pass.  The same code runs
-// with all slabs in one process (device-to-device copies) or with one slab per process (RCCL).
+// and the Poisson solve couples the slabs along t (tri.hip, or slab <-> pencil transposes).  The same code
+// runs with all slabs in one process -- each slab on its own device with its own streams, peer copies between
+// them (dotsocp_create_multi; on one device: dotsocp_create(..., nslabs)) -- or with one slab per process (RCCL).
 #include "solver.h"
 
 #include <algorithm>
@@ -19,6 +20,8 @@ namespace dotsocp {
 
 thread_local std::string g_last_error;
 
+static int make_eig_table(double **dev, i64 n);
+
 void set_error(const char *fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -28,8 +31,131 @@ void set_error(const char *fmt, ...) {
     g_last_error = buf;
 }
 
+int Solver::use_dev(int d) {
+    if (cur_dev == d) return 0;
+    DS_HIP(hipSetDevice(d));
+    cur_dev = d;
+    return 0;
+}
+
+int Solver::use(const Slab &s) { return use_dev(s.dev); }
+
+int Solver::sync_all() {
+    for (auto &s : slabs) {
+        DS_CHECK(use(s));
+        if (s.st_z) DS_HIP(hipStreamSynchronize(s.st_z));
+        if (s.st) DS_HIP(hipStreamSynchronize(s.st));
+    }
+    if (slabs.empty() && stream) {
+        DS_CHECK(use_dev(device));
+        DS_HIP(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+// The slab's next ordering event (round-robin; a wait captures the record that precedes it, so reuse is safe)
+static hipEvent_t next_xev(Slab &s) {
+    hipEvent_t e = s.xev[s.xev_next];
+    s.xev_next = (s.xev_next + 1) % DS_XEV;
+    return e;
+}
+
+int Solver::xcopy(Slab &from, const double *src, Slab &to, double *dst, i64 count) {
+    if (count <= 0) return 0;
+    const size_t bytes = sizeof(double) * (size_t)count;
+    if (from.st == to.st) {
+        DS_CHECK(use(to));
+        DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
+        return 0;
+    }
+    hipEvent_t a = next_xev(from), b = next_xev(to);
+    DS_CHECK(use(from));
+    DS_HIP(hipEventRecord(a, from.st));
+    DS_CHECK(use(to));
+    DS_HIP(hipStreamWaitEvent(to.st, a, 0));
+    if (from.dev == to.dev) DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
+    else DS_HIP(hipMemcpyPeerAsync(dst, to.dev, src, from.dev, bytes, to.st));
+    DS_HIP(hipEventRecord(b, to.st));
+    DS_CHECK(use(from));
+    DS_HIP(hipStreamWaitEvent(from.st, b, 0));
+    return 0;
+}
+
+int Solver::xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, double *dst, size_t dpitch, size_t width,
+                    size_t height) {
+    if (width == 0 || height == 0) return 0;
+    if (from.st == to.st) {
+        DS_CHECK(use(to));
+        DS_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+        return 0;
+    }
+    hipEvent_t a = next_xev(from), b = next_xev(to);
+    DS_CHECK(use(from));
+    DS_HIP(hipEventRecord(a, from.st));
+    DS_CHECK(use(to));
+    DS_HIP(hipStreamWaitEvent(to.st, a, 0));
+    // different devices: peer access was enabled in both directions when the slabs were placed (alloc_slabs)
+    DS_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+    DS_HIP(hipEventRecord(b, to.st));
+    DS_CHECK(use(from));
+    DS_HIP(hipStreamWaitEvent(from.st, b, 0));
+    return 0;
+}
+
+// second streams: fork behind everything enqueued on the slab's main stream ...
+int Solver::fork_z(bool also_halo_event) {
+    (void)also_halo_event;
+    FOR_SLABS(s) {
+        DS_HIP(hipEventRecord(s.ev_fork, s.st));
+        DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
+    }
+    return 0;
+}
+
+// ... and make the main stream wait for what the second one has been given since
+int Solver::join_z() {
+    FOR_SLABS(s) {
+        DS_HIP(hipEventRecord(s.ev_join, s.st_z));
+        DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
+    }
+    return 0;
+}
+
+DevRes *Solver::res_for(int dev) {
+    for (auto *r : devres)
+        if (r->dev == dev) return r;
+    if (use_dev(dev) != 0) return nullptr;
+    DevRes *r = new DevRes();
+    r->dev = dev;
+    r->py = dct_plan_create(ny);
+    r->px = dct_plan_create(nx);
+    r->pt = dct_plan_create(nt);
+    if (!r->py || !r->px || !r->pt || make_eig_table(&r->cy, ny) != 0 || make_eig_table(&r->cx, nx) != 0 ||
+        make_eig_table(&r->ct, nt) != 0) {
+        set_error("DCT plan allocation failed on device %d", dev);
+        dct_plan_destroy(r->py); dct_plan_destroy(r->px); dct_plan_destroy(r->pt);
+        dfree(r->cy); dfree(r->cx); dfree(r->ct);
+        delete r;
+        return nullptr;
+    }
+    devres.push_back(r);
+    return r;
+}
+
 void Solver::free_slabs() {
     for (auto &s : slabs) {
+        (void)use(s);
+        if (s.st_z) (void)hipStreamSynchronize(s.st_z);
+        if (s.st) (void)hipStreamSynchronize(s.st);
+        for (auto &e : s.xev) if (e) (void)hipEventDestroy(e);
+        if (s.st != stream) {        // slab 0 borrows the solver's own streams / events
+            if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
+            if (s.ev_join) (void)hipEventDestroy(s.ev_join);
+            if (s.ev_halo) (void)hipEventDestroy(s.ev_halo);
+            if (s.st_z) (void)hipStreamDestroy(s.st_z);
+            if (s.st) (void)hipStreamDestroy(s.st);
+        }
+        if (s.h_sums) (void)hipHostFree(s.h_sums);
         dfree(s.phi); dfree(s.q); dfree(s.alpha); dfree(s.z); dfree(s.beta); dfree(s.c); dfree(s.weight);
         dfree(s.w0); dfree(s.w1); dfree(s.pencil); dfree(s.pencil2); dfree(s.stage);
         dfree(s.u0_prev); dfree(s.tail_bx); dfree(s.tail_by);
@@ -45,14 +171,19 @@ void Solver::free_slabs() {
 }
 
 Solver::~Solver() {
-    if (stream) {                 // init() got as far as the device: release what lives there
-        (void)hipSetDevice(device);
-        (void)hipStreamSynchronize(stream);
-    }
+    cur_dev = -1;
+    if (stream) (void)sync_all();   // init() got as far as the device: release what lives there
     if (nccl) (void)rccl_api().CommDestroy((ncclComm_t)nccl);
     free_slabs();
-    dct_plan_destroy(py); dct_plan_destroy(px); dct_plan_destroy(pt);
-    dfree(cy); dfree(cx); dfree(ct); dfree(d_red);
+    for (auto *r : devres) {
+        (void)use_dev(r->dev);
+        dct_plan_destroy(r->py); dct_plan_destroy(r->px); dct_plan_destroy(r->pt);
+        dfree(r->cy); dfree(r->cx); dfree(r->ct);
+        delete r;
+    }
+    devres.clear();
+    (void)use_dev(device);
+    dfree(d_red);
     if (h_sums) (void)hipHostFree(h_sums);
     for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -90,7 +221,7 @@ static void pencil_range(i64 plane, int world, int j, i64 *l0, i64 *l1) {
     *l1 = cut(j + 1);
 }
 
-int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
+int Solver::init(const dotsocp_problem *p, int dev, int nslabs, bool multi_dev) {
     DS_ARG(p != nullptr, "prob is NULL");
     DS_ARG(p->dim == 1 || p->dim == 2, "prob.dim must be 1 or 2");
     DS_ARG(p->nt >= 2 && p->nx >= 1, "grid too small");
@@ -111,7 +242,10 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
         return DOTSOCP_ENODEVICE;
     }
     DS_ARG(dev >= 0 && dev < ndev, "device ordinal out of range");
-    DS_HIP(hipSetDevice(dev));
+    ndev_visible = ndev;
+    multi_device = multi_dev && nslabs > 1;
+    cur_dev = -1;
+    DS_CHECK(use_dev(dev));
     DS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     DS_HIP(hipStreamCreateWithFlags(&stream_z, hipStreamNonBlocking));
     DS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -123,16 +257,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
     if (const char *e = getenv("DOTSOCP_TSOLVE")) tri_tsolve = (strcmp(e, "dct") != 0);
     DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
     DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
-    py = dct_plan_create(ny);
-    px = dct_plan_create(nx);
-    pt = dct_plan_create(nt);
-    if (!py || !px || !pt) {
-        set_error("DCT plan allocation failed");
-        return DOTSOCP_EHIP;
-    }
-    DS_CHECK(make_eig_table(&cy, ny));
-    DS_CHECK(make_eig_table(&cx, nx));
-    DS_CHECK(make_eig_table(&ct, nt));
+    if (!res_for(dev)) return DOTSOCP_EHIP;
     world = nslabs;
     rank = 0;
     // device arrays are allocated on first use (upload / begin) or by attach_rccl(), so that a process
@@ -142,9 +267,8 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs) {
 
 int Solver::ensure_alloc() {
     if (!slabs.empty()) return 0;
-    DS_HIP(hipSetDevice(device));
     DS_CHECK(alloc_slabs(remote() ? rank : 0, remote() ? 1 : world));
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_CHECK(sync_all());
     return 0;
 }
 
@@ -155,30 +279,47 @@ int Solver::alloc_slabs(int first, int count) {
     for (int r = 0; r < count; ++r) {
         Slab &s = slabs[r];
         s.index = first + r;
+        // placement: dotsocp_create_multi deals the slabs round-robin over the visible devices, starting at `device`
+        s.dev = (multi_device && !remote()) ? (device + r) % ndev_visible : device;
+        DS_CHECK(use(s));
+        if (r == 0) {
+            s.st = stream; s.st_z = stream_z;
+            s.ev_fork = ev_fork; s.ev_join = ev_join; s.ev_halo = ev_halo;
+        } else {
+            DS_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+            DS_HIP(hipStreamCreateWithFlags(&s.st_z, hipStreamNonBlocking));
+            DS_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+            DS_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+            DS_HIP(hipEventCreateWithFlags(&s.ev_halo, hipEventDisableTiming));
+        }
+        for (auto &e : s.xev) DS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DS_HIP(hipHostMalloc((void **)&s.h_sums, sizeof(double) * S_COUNT));
+        s.res = res_for(s.dev);
+        if (!s.res) return DOTSOCP_EHIP;
         i64 t0, t1;
         dotsocp_slab_range_impl(nt, world, s.index, &t0, &t1);
         s.g.set(ny, nx, nt, t0, t1 - t0);
         const Grid &g = s.g;
-        DS_CHECK(dzalloc(&s.phi, g.NphiAlloc, stream));
-        DS_CHECK(dzalloc(&s.q, g.NqAlloc, stream));
-        DS_CHECK(dzalloc(&s.alpha, g.NqAlloc, stream));
-        DS_CHECK(dzalloc(&s.z, 10 * g.Nz, stream));
-        DS_CHECK(dzalloc(&s.beta, 10 * g.Nz, stream));
-        DS_CHECK(dzalloc(&s.c, g.Nphi, stream));
+        DS_CHECK(dzalloc(&s.phi, g.NphiAlloc, s.st));
+        DS_CHECK(dzalloc(&s.q, g.NqAlloc, s.st));
+        DS_CHECK(dzalloc(&s.alpha, g.NqAlloc, s.st));
+        DS_CHECK(dzalloc(&s.z, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.beta, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.c, g.Nphi, s.st));
         DS_CHECK(dmalloc(&s.w0, g.Nphi));
         DS_CHECK(dmalloc(&s.w1, g.Nphi));
-        if (prob.weighted) DS_CHECK(dzalloc(&s.weight, g.NqAlloc, stream));
+        if (prob.weighted) DS_CHECK(dzalloc(&s.weight, g.NqAlloc, s.st));
         if (fused) {
             fused_geometry(g, s.fg);
-            DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, stream));
-            DS_CHECK(dzalloc(&s.q2, g.NqAlloc, stream));
+            DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, s.st));
+            DS_CHECK(dzalloc(&s.q2, g.NqAlloc, s.st));
             DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
-            DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, stream));
-            DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, stream));
-            DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, stream));
+            DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, s.st));
+            DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, s.st));
+            DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, s.st));
         }
         s.kw.maxBlocks = kkt_partials_needed(g);
-        DS_CHECK(dzalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT, stream));
+        DS_CHECK(dzalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT, s.st));
         DS_CHECK(dmalloc(&s.kw.sums, S_COUNT));
         pencil_range(plane, world, s.index, &s.l0, &s.nl);
         s.nl -= s.l0;
@@ -187,22 +328,31 @@ int Solver::alloc_slabs(int first, int count) {
             DS_CHECK(dmalloc(&s.pencil2, s.nl * nt));
             DS_CHECK(dmalloc(&s.stage, g.Nphi));
             if (!g.first) {
-                DS_CHECK(dzalloc(&s.u0_prev, plane, stream));
-                DS_CHECK(dzalloc(&s.a0_prev, plane, stream));
-                DS_CHECK(dzalloc(&s.a0w_prev, plane, stream));
-                DS_CHECK(dzalloc(&s.tail_bx, g.bxLayer, stream));
-                DS_CHECK(dzalloc(&s.btail_bx, g.bxLayer, stream));
-                DS_CHECK(dzalloc(&s.tail_by, g.byLayer, stream));
-                DS_CHECK(dzalloc(&s.btail_by, g.byLayer, stream));
+                DS_CHECK(dzalloc(&s.u0_prev, plane, s.st));
+                DS_CHECK(dzalloc(&s.a0_prev, plane, s.st));
+                DS_CHECK(dzalloc(&s.a0w_prev, plane, s.st));
+                DS_CHECK(dzalloc(&s.tail_bx, g.bxLayer, s.st));
+                DS_CHECK(dzalloc(&s.btail_bx, g.bxLayer, s.st));
+                DS_CHECK(dzalloc(&s.tail_by, g.byLayer, s.st));
+                DS_CHECK(dzalloc(&s.btail_by, g.byLayer, s.st));
             }
             if (!g.last) {
-                DS_CHECK(dzalloc(&s.send_plane, plane, stream));
-                DS_CHECK(dzalloc(&s.send_plane2, plane, stream));
-                DS_CHECK(dzalloc(&s.send_bx, g.bxLayer, stream));
-                DS_CHECK(dzalloc(&s.send_by, g.byLayer, stream));
+                DS_CHECK(dzalloc(&s.send_plane, plane, s.st));
+                DS_CHECK(dzalloc(&s.send_plane2, plane, s.st));
+                DS_CHECK(dzalloc(&s.send_bx, g.bxLayer, s.st));
+                DS_CHECK(dzalloc(&s.send_by, g.byLayer, s.st));
             }
         }
     }
+    // neighbours on different devices copy layers into each other's memory
+    for (auto &a : slabs)
+        for (auto &b : slabs) {
+            if (a.dev == b.dev) continue;
+            DS_CHECK(use(a));
+            hipError_t e = hipDeviceEnablePeerAccess(b.dev, 0);
+            // a refusal is not fatal: hipMemcpyPeerAsync stages through the host without peer access
+            if (e != hipSuccess) (void)hipGetLastError();
+        }
     return 0;
 }
 
@@ -216,7 +366,8 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
         return DOTSOCP_ESTATE;
     }
     if (!fused) { set_error("time slabs need the fused dataflow (unset DOTSOCP_FUSED=0)"); return DOTSOCP_EINVAL; }
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     Rccl &api = rccl_api();
     DS_CHECK(api.load());
     ncclUniqueId uid;
@@ -239,8 +390,10 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
         DS_HIP(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, stream));
         DS_NCCL(api.AllReduce(d, d + 2, 1, ncclDouble, ncclSum, comm, stream));
         DS_NCCL(api.GroupStart());
-        if (rk + 1 < wd) DS_NCCL(api.Send(d + 1, 1, ncclDouble, rk + 1, comm, stream));
-        if (rk > 0) DS_NCCL(api.Recv(d + 3, 1, ncclDouble, rk - 1, comm, stream));
+        ++open_groups;
+        if (rk + 1 < wd) DS_NCCL_G(api.Send(d + 1, 1, ncclDouble, rk + 1, comm, stream));
+        if (rk > 0) DS_NCCL_G(api.Recv(d + 3, 1, ncclDouble, rk - 1, comm, stream));
+        --open_groups;
         DS_NCCL(api.GroupEnd());
         DS_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, stream));
         DS_HIP(hipStreamSynchronize(stream));
@@ -263,7 +416,7 @@ int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
         for (size_t i = 0; i + 1 < slabs.size(); ++i) {
             Slab &from = (dir > 0) ? slabs[i] : slabs[i + 1];
             Slab &to = (dir > 0) ? slabs[i + 1] : slabs[i];
-            DS_HIP(hipMemcpyAsync(dst(to), src(from), sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+            DS_CHECK(xcopy(from, src(from), to, dst(to), count));
         }
         return 0;
     }
@@ -271,8 +424,10 @@ int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
     Slab &s = slabs[0];
     const int to = rank + dir, from = rank - dir;
     DS_NCCL(api.GroupStart());
-    if (to >= 0 && to < world) DS_NCCL(api.Send(src(s), (size_t)count, ncclDouble, to, (ncclComm_t)nccl, stream));
-    if (from >= 0 && from < world) DS_NCCL(api.Recv(dst(s), (size_t)count, ncclDouble, from, (ncclComm_t)nccl, stream));
+    ++open_groups;
+    if (to >= 0 && to < world) DS_NCCL_G(api.Send(src(s), (size_t)count, ncclDouble, to, (ncclComm_t)nccl, stream));
+    if (from >= 0 && from < world) DS_NCCL_G(api.Recv(dst(s), (size_t)count, ncclDouble, from, (ncclComm_t)nccl, stream));
+    --open_groups;
     DS_NCCL(api.GroupEnd());
     return 0;
 }
@@ -289,12 +444,18 @@ int Solver::shift_edge_halo(const Sel &base) {
 // Several shift() calls issued as ONE RCCL group (nested groups are legal): traffic to the left and
 // to the right neighbour then shares the bidirectional links instead of queueing behind each other.
 int Solver::group_begin() {
-    if (remote()) DS_NCCL(rccl_api().GroupStart());
+    if (remote()) {
+        DS_NCCL(rccl_api().GroupStart());
+        ++open_groups;
+    }
     return 0;
 }
 
 int Solver::group_end() {
-    if (remote()) DS_NCCL(rccl_api().GroupEnd());
+    if (remote()) {
+        --open_groups;
+        DS_NCCL(rccl_api().GroupEnd());
+    }
     return 0;
 }
 
@@ -302,7 +463,10 @@ int Solver::group_end() {
 int Solver::exchange_u0_tail() {
     if (!multi()) return 0;
     for (auto &s : slabs)
-        if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q, s.alpha, s.weight, s.send_plane, stream));
+        if (!s.g.last) {
+            DS_CHECK(use(s));
+            DS_CHECK(launch_u0_tail(s.g, s.q, s.alpha, s.weight, s.send_plane, s.st));
+        }
     DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
     u0_fresh = true;
     return 0;
@@ -341,11 +505,11 @@ int Solver::transpose(bool forward) {
                 double *penPtr = p.pencil + p.nl * s.g.t0;        // layer pitch p.nl
                 if (p.nl <= 0) continue;
                 if (forward)
-                    DS_HIP(hipMemcpy2DAsync(penPtr, sizeof(double) * p.nl, slabPtr, sizeof(double) * plane,
-                                            sizeof(double) * p.nl, s.g.ntl, hipMemcpyDeviceToDevice, stream));
+                    DS_CHECK(xcopy2d(s, slabPtr, sizeof(double) * plane, p, penPtr, sizeof(double) * p.nl,
+                                     sizeof(double) * p.nl, (size_t)s.g.ntl));
                 else
-                    DS_HIP(hipMemcpy2DAsync(slabPtr, sizeof(double) * plane, penPtr, sizeof(double) * p.nl,
-                                            sizeof(double) * p.nl, s.g.ntl, hipMemcpyDeviceToDevice, stream));
+                    DS_CHECK(xcopy2d(p, penPtr, sizeof(double) * p.nl, s, slabPtr, sizeof(double) * plane,
+                                     sizeof(double) * p.nl, (size_t)s.g.ntl));
             }
         return 0;
     }
@@ -379,24 +543,28 @@ int Solver::transpose(bool forward) {
         DS_CHECK(launch_pencil_pack(true, pc, plane, s.g.ntl, s.w0, s.stage, stream));
         DS_CHECK(self_copy(true));
         DS_NCCL(api.GroupStart());
+        ++open_groups;
         for (int j = 0; j < world; ++j) {
             if (j == rank) continue;
             if (pnl[j] > 0)
-                DS_NCCL(api.Send(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Send(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
             if (s.nl > 0)
-                DS_NCCL(api.Recv(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Recv(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
         }
+        --open_groups;
         DS_NCCL(api.GroupEnd());
     } else {
         DS_CHECK(self_copy(false));
         DS_NCCL(api.GroupStart());
+        ++open_groups;
         for (int j = 0; j < world; ++j) {
             if (j == rank) continue;
             if (s.nl > 0)
-                DS_NCCL(api.Send(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Send(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
             if (pnl[j] > 0)
-                DS_NCCL(api.Recv(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Recv(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
         }
+        --open_groups;
         DS_NCCL(api.GroupEnd());
         DS_CHECK(launch_pencil_pack(false, pc, plane, s.g.ntl, s.w0, s.stage, stream));
     }
@@ -424,11 +592,12 @@ int Solver::tri_alloc() {
     const i64 plane = ny * nx;
     for (auto &s : slabs) {
         if (s.tri_send) continue;
-        DS_CHECK(dzalloc(&s.tri_send, 2 * plane + (i64)TRI_EXTRA * world, stream));
-        DS_CHECK(dzalloc(&s.tri_brecv, 2 * plane + (i64)TRI_EXTRA * world, stream));
-        DS_CHECK(dzalloc(&s.tri_recv, (2 * s.nl + TRI_EXTRA) * world, stream));
-        DS_CHECK(dzalloc(&s.tri_bsend, (2 * s.nl + TRI_EXTRA) * world, stream));
-        DS_CHECK(dzalloc(&s.tri_zero, nt, stream));
+        DS_CHECK(use(s));
+        DS_CHECK(dzalloc(&s.tri_send, 2 * plane + (i64)TRI_EXTRA * world, s.st));
+        DS_CHECK(dzalloc(&s.tri_brecv, 2 * plane + (i64)TRI_EXTRA * world, s.st));
+        DS_CHECK(dzalloc(&s.tri_recv, (2 * s.nl + TRI_EXTRA) * world, s.st));
+        DS_CHECK(dzalloc(&s.tri_bsend, (2 * s.nl + TRI_EXTRA) * world, s.st));
+        DS_CHECK(dzalloc(&s.tri_zero, nt, s.st));
     }
     return 0;
 }
@@ -447,7 +616,8 @@ int Solver::tri_exchange(bool back) {
                 const int p = sp.index, j = sj.index;
                 double *a = sp.tri_send + off(j), *b = sj.tri_recv + (i64)p * cnt(j);
                 if (back) { a = sj.tri_bsend + (i64)p * cnt(j); b = sp.tri_brecv + off(j); }
-                DS_HIP(hipMemcpyAsync(b, a, sizeof(double) * (size_t)cnt(j), hipMemcpyDeviceToDevice, stream));
+                if (back) DS_CHECK(xcopy(sj, a, sp, b, cnt(j)));
+                else DS_CHECK(xcopy(sp, a, sj, b, cnt(j)));
             }
         return 0;
     }
@@ -459,16 +629,18 @@ int Solver::tri_exchange(bool back) {
         DS_HIP(hipMemcpyAsync(b, a, sizeof(double) * (size_t)cnt(rank), hipMemcpyDeviceToDevice, stream));
     }
     DS_NCCL(api.GroupStart());
+    ++open_groups;
     for (int j = 0; j < world; ++j) {
         if (j == rank) continue;
         if (!back) {
-            DS_NCCL(api.Send(s.tri_send + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
-            DS_NCCL(api.Recv(s.tri_recv + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL_G(api.Send(s.tri_send + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL_G(api.Recv(s.tri_recv + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
         } else {
-            DS_NCCL(api.Send(s.tri_bsend + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
-            DS_NCCL(api.Recv(s.tri_brecv + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL_G(api.Send(s.tri_bsend + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL_G(api.Recv(s.tri_brecv + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
         }
     }
+    --open_groups;
     DS_NCCL(api.GroupEnd());
     return 0;
 }
@@ -480,17 +652,17 @@ int Solver::poisson_t_tridiag() {
     std::vector<i64> slab_n;
     tri_layout(plane, nt, world, pc, slab_n);
     const double kscale = D * D;
-    for (auto &s : slabs) DS_CHECK(launch_tri_local(s.g, nt, kscale, cy, cx, pc, s.w0, s.tri_send, stream));
+    FOR_SLABS(s) DS_CHECK(launch_tri_local(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.w0, s.tri_send, s.st));
     prof_begin(PH_TRANSPOSE);
     DS_CHECK(tri_exchange(false));
     prof_end(PH_TRANSPOSE);
-    for (auto &s : slabs)
-        DS_CHECK(launch_tri_reduced(s.g, nt, kscale, cy, cx, pc, s.index, s.l0, s.nl, slab_n.data(), s.tri_recv, s.tri_bsend,
-                                    s.tri_zero, stream));
+    FOR_SLABS(s)
+        DS_CHECK(launch_tri_reduced(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.index, s.l0, s.nl, slab_n.data(), s.tri_recv,
+                                    s.tri_bsend, s.tri_zero, s.st));
     prof_begin(PH_TRANSPOSE);
     DS_CHECK(tri_exchange(true));
     prof_end(PH_TRANSPOSE);
-    for (auto &s : slabs) DS_CHECK(launch_tri_final(s.g, nt, kscale, cy, cx, pc, s.tri_brecv, s.w0, s.w1, stream));
+    FOR_SLABS(s) DS_CHECK(launch_tri_final(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.tri_brecv, s.w0, s.w1, s.st));
     return 0;
 }
 
@@ -520,13 +692,16 @@ static int copy_field(Solver &S, int field, double *host, bool up) {
     if (S.remote()) { ntn = S.slabs[0].g.ntl; ntc = S.slabs[0].g.ncl; }
     const i64 NzG = ny * nx * ntc;
     const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * ntn;
+    hipStream_t cur = nullptr;
     auto cp = [&](double *dev, double *h, i64 n) -> int {
         if (n <= 0) return 0;
-        if (up) DS_HIP(hipMemcpyAsync(dev, h, sizeof(double) * n, hipMemcpyHostToDevice, S.stream));
-        else DS_HIP(hipMemcpyAsync(h, dev, sizeof(double) * n, hipMemcpyDeviceToHost, S.stream));
+        if (up) DS_HIP(hipMemcpyAsync(dev, h, sizeof(double) * n, hipMemcpyHostToDevice, cur));
+        else DS_HIP(hipMemcpyAsync(h, dev, sizeof(double) * n, hipMemcpyDeviceToHost, cur));
         return 0;
     };
     for (auto &s : S.slabs) {
+        DS_CHECK(S.use(s));
+        cur = s.st;
         const Grid &g = s.g;
         const i64 t0 = S.remote() ? 0 : g.t0;
         switch (field) {
@@ -542,7 +717,7 @@ static int copy_field(Solver &S, int field, double *host, bool up) {
             case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
                 double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
                 const int K = S.prob.dim == 1 ? 6 : 10;
-                if (up && S.prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, S.stream));
+                if (up && S.prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, cur));
                 for (int j = 0; j < K; ++j) {
                     const int pj = S.prob.dim == 1 ? k1dCols[j] : j;
                     DS_CHECK(cp(d + pj * g.Nz, host + j * NzG + g.plane * t0, g.Nz));
@@ -551,7 +726,7 @@ static int copy_field(Solver &S, int field, double *host, bool up) {
             }
         }
     }
-    DS_HIP(hipStreamSynchronize(S.stream));
+    DS_CHECK(S.sync_all());
     return 0;
 }
 
@@ -560,7 +735,8 @@ int Solver::upload(int field, const double *host) {
     DS_ARG(field_len(field) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "weight uploaded to an unweighted problem");
     if (begun) { set_error("upload() after begin()"); return DOTSOCP_ESTATE; }
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     DS_CHECK(ensure_alloc());
     return copy_field(*this, field, const_cast<double *>(host), true);
 }
@@ -569,7 +745,8 @@ int Solver::download(int field, double *host) {
     DS_ARG(host != nullptr, "host pointer is NULL");
     DS_ARG(field_len(field) >= 0, "unknown field");
     DS_ARG(field != DOTSOCP_F_WEIGHT || prob.weighted, "no weight in an unweighted problem");
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     DS_CHECK(ensure_alloc());
     if (field == DOTSOCP_F_Z || field == DOTSOCP_F_BETA) {
         DS_CHECK(ensure_z());
@@ -587,9 +764,10 @@ int Solver::download(int field, double *host) {
 // --------------------------------------------------------------------------------------
 // profiling helpers
 // --------------------------------------------------------------------------------------
-void Solver::prof_begin(int phase, hipStream_t st) {
+void Solver::prof_begin(int phase, bool on_z) {
     if (!profiling) return;
-    if (!st) st = stream;
+    (void)use_dev(device);
+    hipStream_t st = on_z ? stream_z : stream;
     Pending p;
     p.phase = phase;
     auto get = [&]() {
@@ -604,15 +782,18 @@ void Solver::prof_begin(int phase, hipStream_t st) {
     pending.push_back(p);
 }
 
-void Solver::prof_end(int phase, hipStream_t st) {
+void Solver::prof_end(int phase, bool on_z) {
     if (!profiling) return;
-    if (!st) st = stream;
+    (void)use_dev(device);
+    hipStream_t st = on_z ? stream_z : stream;
     for (auto it2 = pending.rbegin(); it2 != pending.rend(); ++it2)
         if (it2->phase == phase) { (void)hipEventRecord(it2->b, st); break; }
 }
 
 int Solver::prof_flush() {
     if (!profiling || pending.empty()) return 0;
+    DS_CHECK(use_dev(device));
+    DS_HIP(hipStreamSynchronize(stream_z));
     DS_HIP(hipStreamSynchronize(stream));
     for (auto &p : pending) {
         float ms = 0.f;
@@ -652,7 +833,7 @@ void Solver::update_coef() {
 
 int Solver::flush_beta() {
     if (!bpend) return 0;
-    for (auto &s : slabs) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul, bdiv, stream));
+    FOR_SLABS(s) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul, bdiv, s.st));
     bpend = false;
     return 0;
 }
@@ -667,14 +848,14 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
         bmul = a_mul;
         bdiv = a_div;
     }
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         const Grid &g = s.g;
-        if (with_c) DS_CHECK(launch_scale(s.c, g.Nphi, a_mul, a_div, stream));
-        DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, stream));
-        if (!(fused && begun)) DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, stream));
+        if (with_c) DS_CHECK(launch_scale(s.c, g.Nphi, a_mul, a_div, s.st));
+        DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, s.st));
+        if (!(fused && begun)) DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, s.st));
         if (q_div != 1.0) {
-            DS_CHECK(launch_scale(s.q, g.NqAlloc, 1.0, q_div, stream));
-            DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, stream));
+            DS_CHECK(launch_scale(s.q, g.NqAlloc, 1.0, q_div, s.st));
+            DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, s.st));
         }
     }
     return 0;
@@ -697,7 +878,8 @@ int Solver::begin(const dotsocp_opts *o) {
     DS_ARG(o->maxit >= 0, "opts.maxit < 0");
     DS_ARG(o->sigma > 0, "opts.sigma must be positive");
     if (begun) { set_error("begin() called twice"); return DOTSOCP_ESTATE; }
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     DS_CHECK(ensure_alloc());
     if (method == DOTSOCP_METHOD_ACCADMM) {
         DS_CHECK(acc_alloc());
@@ -741,11 +923,11 @@ int Solver::begin(const dotsocp_opts *o) {
 // phi = idctn(dctn(rhs) ./ kernel), kernel = D^2 * initialize_FFTkernel  (:96,194); rhs is in w0
 int Solver::poisson_all() {
     const i64 plane = ny * nx;
-    const bool tp2 = dct_plan_is_pow2(pt);
-    for (auto &s : slabs) {
+    const bool tp2 = dct_plan_is_pow2(devres[0]->pt);
+    FOR_SLABS(s) {
         const Grid &g = s.g;
-        DS_CHECK(launch_dct_axis(py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, stream));
-        DS_CHECK(launch_dct_axis(px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, stream));
+        DS_CHECK(launch_dct_axis(s.res->py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, s.st));
+        DS_CHECK(launch_dct_axis(s.res->px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, s.st));
     }
     bool tri = multi() && tri_tsolve && world <= DS_MAX_WORLD;
     for (auto &s : slabs) tri = tri && s.g.ntl <= TRI_EXTRA;
@@ -757,15 +939,15 @@ int Solver::poisson_all() {
         DS_CHECK(transpose(true));
         prof_end(PH_TRANSPOSE);
     }
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         double *p = multi() ? s.pencil : s.w0;
         double *p2 = multi() ? s.pencil2 : s.w1;
         if (tp2) {
-            DS_CHECK(launch_dct_t_solve(pt, p, p, ny, plane, s.l0, s.nl, nt, D * D, cy, cx, ct, stream));
+            DS_CHECK(launch_dct_t_solve(s.res->pt, p, p, ny, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
         } else {
-            DS_CHECK(launch_dct_axis(pt, p, p2, s.nl, 1, nt, 2, 0, stream));
-            DS_CHECK(launch_spectral_divide_pencil(p2, ny, plane, s.l0, s.nl, nt, D * D, cy, cx, ct, stream));
-            DS_CHECK(launch_dct_axis(pt, p2, p, s.nl, 1, nt, 2, 1, stream));
+            DS_CHECK(launch_dct_axis(s.res->pt, p, p2, s.nl, 1, nt, 2, 0, s.st));
+            DS_CHECK(launch_spectral_divide_pencil(p2, ny, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
+            DS_CHECK(launch_dct_axis(s.res->pt, p2, p, s.nl, 1, nt, 2, 1, s.st));
         }
     }
     if (multi()) {
@@ -774,10 +956,10 @@ int Solver::poisson_all() {
         prof_end(PH_TRANSPOSE);
     }
     }
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         const Grid &g = s.g;
-        DS_CHECK(launch_dct_axis(px, s.w0, s.w1, g.ny, g.nx, g.ntl, 1, 1, stream));
-        DS_CHECK(launch_dct_axis(py, s.w1, s.phi, g.ny, g.nx, g.ntl, 0, 1, stream));
+        DS_CHECK(launch_dct_axis(s.res->px, s.w0, s.w1, g.ny, g.nx, g.ntl, 1, 1, s.st));
+        DS_CHECK(launch_dct_axis(s.res->py, s.w1, s.phi, g.ny, g.nx, g.ntl, 0, 1, s.st));
     }
     return 0;
 }
@@ -791,11 +973,11 @@ int Solver::phase_phi() {
     }
     prof_begin(PH_RHS);
     if (!rhs_valid) {
-        for (auto &s : slabs) DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, stream));
+        FOR_SLABS(s) DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, s.st));
     } else if (multi()) {
         // the q-step left rhs in w0; its first layer still lacks the left neighbour's last cell
-        for (auto &s : slabs)
-            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, stream));
+        FOR_SLABS(s)
+            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, s.st));
     }
     rhs_valid = false;
     prof_end(PH_RHS);
@@ -805,21 +987,22 @@ int Solver::phase_phi() {
     return 0;                        // the phi head travels with the adjoint tails (phase_z_tails)
 }
 
-// The cone pass needs q^k and beta only -- not phi^{k+1} -- so it may run on `st` = stream_z
-// concurrently with the phi step (rhs, Poisson solve and, in time-slab mode, its transposes).
-int Solver::phase_z(hipStream_t st, int part) {
+// The cone pass needs q^k and beta only -- not phi^{k+1} -- so it may run on every slab's second stream
+// (on_z) concurrently with the phi step (rhs, Poisson solve and, in time-slab mode, its exchanges).
+int Solver::phase_z(bool on_z, int part) {
     if (part != 1) DS_CHECK(ensure_halo());     // the last chunk reads the q halo (part 1 never does)
     if (!fused) {
-        prof_begin(PH_PROJ, st);
-        for (auto &s : slabs) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, st));
-        prof_end(PH_PROJ, st);
+        prof_begin(PH_PROJ, on_z);
+        FOR_SLABS(s) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, on_z ? s.st_z : s.st));
+        prof_end(PH_PROJ, on_z);
         return 0;
     }
     const int ph = deferred ? PH_FUSED_B : PH_FUSED_A;
     z_valid = false;          // the fused pass forms z^{k+1} in registers only
     z_prev_ok = false;        // ... and (mode B) overwrites the kept beta^{k-1}
-    if (part != 2) prof_begin(ph, st);
-    for (auto &s : slabs) {
+    if (part != 2) prof_begin(ph, on_z);
+    FOR_SLABS(s) {
+        hipStream_t st = on_z ? s.st_z : s.st;
         FusedArgs a{};
         a.q = s.q;
         a.q2 = s.q2;
@@ -840,7 +1023,7 @@ int Solver::phase_z(hipStream_t st, int part) {
         }
     }
     if (part == 1) return 0;
-    prof_end(ph, st);
+    prof_end(ph, on_z);
     if (deferred) bpend = false;      // mode B rewrote beta with the scaling applied
     return 0;
 }
@@ -854,8 +1037,8 @@ int Solver::ship_tails() {
     if (multi()) {
         // adjoint sums of every slab's last cell for the first edge layer of its right neighbour
         prof_begin(PH_COMM);
-        for (auto &s : slabs)
-            if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.q2, s.sx, s.sy, s.send_bx, s.send_by, stream));
+        FOR_SLABS(s)
+            if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.q2, s.sx, s.sy, s.send_bx, s.send_by, s.st));
         DS_CHECK(group_begin());
         // first phi layer of every slab -> halo layer of its left neighbour (forward time difference of the q-step)
         DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
@@ -868,11 +1051,11 @@ int Solver::ship_tails() {
 }
 
 int Solver::phase_q(int part) {
-    hipStream_t st = (part == 1) ? stream_z : stream;
     if (part != 1) prof_begin(PH_QSTEP);
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
+        hipStream_t st = (part == 1) ? s.st_z : s.st;
         if (!fused) {
-            DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, stream));
+            DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, s.st));
         } else {
             // q^{k+1} goes to the buffer that held q^{k-1}; q^k is kept for the deferred beta update
             if (qrhs) {
@@ -886,14 +1069,16 @@ int Solver::phase_q(int part) {
                 if (part != 1) std::swap(s.alpha, s.alpha2);
             } else {
                 DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by,
-                                            s.q_old, s.alpha, stream));
+                                            s.q_old, s.alpha, s.st));
             }
             if (part != 1) std::swap(s.q, s.q_old);
         }
     }
     if (part == 1) return 0;
     prof_end(PH_QSTEP);
-    if (part == 2) DS_HIP(hipStreamWaitEvent(stream, ev_join, 0));     // the middle chunks (stream_z)
+    if (part == 2) {                                                    // the middle chunks (second streams)
+        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
+    }
     rhs_valid = fused && qrhs;
     // the halo exchange waits for the next consumer: the next step() runs it beside the first cone chunks
     if (multi() && fused && overlap && cone_split_enabled()) halo_pending = true;
@@ -907,7 +1092,7 @@ int Solver::phase_mult() {
         return 0;
     }
     prof_begin(PH_BETA);
-    for (auto &s : slabs) DS_CHECK(launch_beta_update(s.g, lc, s.q, s.z, s.beta, stream));
+    FOR_SLABS(s) DS_CHECK(launch_beta_update(s.g, lc, s.q, s.z, s.beta, s.st));
     prof_end(PH_BETA);
     return 0;
 }
@@ -918,7 +1103,7 @@ int Solver::materialise() {
     if (!fused || !deferred) return 0;
     DS_CHECK(ensure_halo());
     prof_begin(PH_MATERIALISE);
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         FusedArgs a{};
         a.q_old = s.q_old;
         a.q = s.q;
@@ -926,7 +1111,7 @@ int Solver::materialise() {
         a.beta_out = s.beta;
         a.z_out = s.z;
         set_pending(a);
-        DS_CHECK(launch_cone_fused(2, s.g, lc, s.fg, a, stream));
+        DS_CHECK(launch_cone_fused(2, s.g, lc, s.fg, a, s.st));
     }
     prof_end(PH_MATERIALISE);
     bpend = false;
@@ -945,7 +1130,7 @@ int Solver::ensure_z() {
     }
     DS_CHECK(ensure_halo());
     prof_begin(PH_MATERIALISE);
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         FusedArgs a{};
         a.q_old = s.q_old;
         a.q = s.q;
@@ -954,7 +1139,7 @@ int Solver::ensure_z() {
         a.bpend = zp_pend ? 1 : 0;
         a.bmul = zp_mul;
         a.bdiv = zp_div;
-        DS_CHECK(launch_cone_fused(3, s.g, lc, s.fg, a, stream));
+        DS_CHECK(launch_cone_fused(3, s.g, lc, s.fg, a, s.st));
     }
     prof_end(PH_MATERIALISE);
     z_valid = true;
@@ -970,20 +1155,20 @@ int Solver::kkt_sums(double *S) {
     k.dsE = dScale / E;
     // the launches below write per-workgroup partial sums into four regions; grids of different
     // shapes may use a region on different calls, so stale entries are cleared first
-    for (auto &s : slabs)
-        DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, stream));
+    FOR_SLABS(s)
+        DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
     // ---- cell part (region 1 of the partial sums) ----
     int rest = 1 | 4 | 8;
     if (fused && deferred) {
         // pending multiplier step + cell sums in one pass; beta^k stays in beta2 so that z can be regenerated
-        for (auto &s : slabs) {
+        FOR_SLABS(s) {
             FusedArgs a{};
             a.q_old = s.q_old;
             a.q = s.q;
             a.beta_in = s.beta;
             a.beta_out = s.beta2;
             set_pending(a);
-            DS_CHECK(launch_kkt_cells_update(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, stream));
+            DS_CHECK(launch_kkt_cells_update(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, s.st));
             std::swap(s.beta, s.beta2);
         }
         // the kept beta^k (now in beta2) is still unscaled in memory: remember its pending op for MODE_Z
@@ -999,10 +1184,10 @@ int Solver::kkt_sums(double *S) {
     }
     if (multi()) {
         const i64 plane = ny * nx;
-        for (auto &s : slabs)
+        FOR_SLABS(s)
             if (!s.g.last)
                 DS_CHECK(launch_kkt_tail(s.g, s.alpha, s.beta, s.weight, s.send_plane, s.send_plane2, s.send_bx, s.send_by,
-                                         stream));
+                                         s.st));
         DS_CHECK(group_begin());
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.a0_prev; }, plane));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane2; }, [](Slab &s) { return s.a0w_prev; }, plane));
@@ -1011,14 +1196,18 @@ int Solver::kkt_sums(double *S) {
         DS_CHECK(group_end());
     }
     for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
-        DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, stream));
-        DS_CHECK(launch_kkt_final(s.g, s.kw, stream));
+        DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, s.st));
+        DS_CHECK(launch_kkt_final(s.g, s.kw, s.st));
         if (remote()) break;
-        DS_HIP(hipMemcpyAsync(h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-        DS_HIP(hipStreamSynchronize(stream));
-        for (int i = 0; i < S_COUNT; ++i) S[i] += h_sums[i];
+        DS_HIP(hipMemcpyAsync(s.h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s.st));
+    }
+    if (!remote()) {        // all slabs are enqueued before the host waits for the first; summed in slab order
+        FOR_SLABS(s) {
+            DS_HIP(hipStreamSynchronize(s.st));
+            for (int i = 0; i < S_COUNT; ++i) S[i] += s.h_sums[i];
+        }
     }
     S[S_COUNT] = elapsed();
     if (remote()) {
@@ -1068,8 +1257,9 @@ int Solver::rescale_block() {
     if (!prob.weighted) norm_d = norm_d / dScale2;      // solver_wsocp_inPALM.m has no norm_d
     // c, alpha, beta <- x * dScale2 / cScale2^2 ; q, z <- x / dScale2
     DS_CHECK(scale_state(dScale2, cScale2 * cScale2, dScale2, true));
-    if (method == DOTSOCP_METHOD_PALM)                   // solver_socp_PALM.m:191 tmp_q = A phi is scaled: scale phi
-        for (auto &s : slabs) DS_CHECK(launch_scale(s.phi, s.g.NphiAlloc, 1.0, dScale2, stream));
+    if (method == DOTSOCP_METHOD_PALM) {                 // solver_socp_PALM.m:191 tmp_q = A phi is scaled: scale phi
+        FOR_SLABS(s) DS_CHECK(launch_scale(s.phi, s.g.NphiAlloc, 1.0, dScale2, s.st));
+    }
     dScale = dScale2 * dScale;
     cScale = cScale2 * cScale;
     sigmaScale = sigmaScale * (cScale2 / dScale2);
@@ -1192,39 +1382,40 @@ int Solver::step(bool *brk) {
     if (split) {
         // as below, and the q halo / u0 tail of the last q-step travel (main stream) while stream_z works on the
         // cone chunks that do not read the halo; only the last chunk of every slab waits for it
-        DS_HIP(hipEventRecord(ev_fork, stream));
+        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_fork, s.st));
         DS_CHECK(ensure_halo());
-        DS_HIP(hipEventRecord(ev_halo, stream));
-        DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
-        DS_CHECK(phase_z(stream_z, 1));
-        DS_HIP(hipStreamWaitEvent(stream_z, ev_halo, 0));
-        DS_CHECK(phase_z(stream_z, 2));
-        DS_HIP(hipEventRecord(ev_join, stream_z));
+        FOR_SLABS(s) {
+            DS_HIP(hipEventRecord(s.ev_halo, s.st));
+            DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
+        }
+        DS_CHECK(phase_z(true, 1));
+        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_halo, 0));
+        DS_CHECK(phase_z(true, 2));
+        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
         DS_CHECK(phase_phi());
-        DS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
     } else if (overlap) {
         // fork: cone pass on stream_z beside the phi step on the main stream, join before the q-step
         DS_CHECK(ensure_halo());
-        DS_HIP(hipEventRecord(ev_fork, stream));
-        DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
-        DS_CHECK(phase_z(stream_z));
-        DS_HIP(hipEventRecord(ev_join, stream_z));
+        DS_CHECK(fork_z());
+        DS_CHECK(phase_z(true));
+        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
         DS_CHECK(phase_phi());
-        DS_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
     } else {
         DS_CHECK(phase_phi());
-        DS_CHECK(phase_z(stream));
+        DS_CHECK(phase_z(false));
     }
     bool split_q = overlap && fused && qrhs && multi() && cone_split_enabled();
     for (auto &s : slabs) split_q = split_q && qstep_rhs_chunks(s.g, s.fg) >= 3;
     if (split_q) {
         // the chunks of the q-step that need neither neighbour run on stream_z while the phi head and the adjoint
         // tails travel on the main stream; the first and the last chunk follow the exchange
-        DS_HIP(hipEventRecord(ev_fork, stream));                 // phi^{k+1} and the cone pass are complete
+        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_fork, s.st));    // phi^{k+1} and the cone pass are complete
         DS_CHECK(phase_z_tails());                               // enqueued first: the exchange gets its CUs at once
-        DS_HIP(hipStreamWaitEvent(stream_z, ev_fork, 0));
+        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
         DS_CHECK(phase_q(1));
-        DS_HIP(hipEventRecord(ev_join, stream_z));
+        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
         DS_CHECK(phase_q(2));
     } else {
         DS_CHECK(phase_z_tails());
@@ -1241,7 +1432,8 @@ int Solver::step(bool *brk) {
 
 int Solver::run(i64 n_iters, i64 *done) {
     if (!begun || finished) { set_error("run() needs begin() and must precede finish()"); return DOTSOCP_ESTATE; }
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     i64 n = 0;
     while (it < opts.maxit && !stopped) {
         if (n_iters >= 0 && n >= n_iters) break;
@@ -1251,7 +1443,7 @@ int Solver::run(i64 n_iters, i64 *done) {
         ++n;
     }
     DS_CHECK(ensure_halo());          // callers between run() calls see exchanged halos
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_CHECK(sync_all());
     DS_CHECK(prof_flush());
     if (done) *done = n;
     return 0;
@@ -1259,10 +1451,11 @@ int Solver::run(i64 n_iters, i64 *done) {
 
 int Solver::finish(dotsocp_result *res) {
     if (!begun) { set_error("finish() before begin()"); return DOTSOCP_ESTATE; }
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     DS_CHECK(ensure_z());
     DS_CHECK(flush_beta());
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_CHECK(sync_all());
     DS_CHECK(prof_flush());
     finished = true;
     if (res) {

@@ -24,36 +24,36 @@
 namespace dotsocp {
 
 int Solver::acc_alloc() {
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         const Grid &g = s.g;
         if (!s.q2) {                              // DOTSOCP_FUSED=0 contexts come without the tile buffers
             fused_geometry(g, s.fg);
-            DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, stream));
-            DS_CHECK(dzalloc(&s.q2, g.NqAlloc, stream));
+            DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, s.st));
+            DS_CHECK(dzalloc(&s.q2, g.NqAlloc, s.st));
             DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
-            DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, stream));
-            DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, stream));
-            DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, stream));
+            DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, s.st));
+            DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, s.st));
+            DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, s.st));
         }
         if (s.phi_p) continue;
-        DS_CHECK(dzalloc(&s.phi_p, g.NphiAlloc, stream));
-        DS_CHECK(dzalloc(&s.alpha_p, g.NqAlloc, stream));
-        DS_CHECK(dzalloc(&s.z_p, 10 * g.Nz, stream));
-        DS_CHECK(dzalloc(&s.phi_a, g.NphiAlloc, stream));
-        DS_CHECK(dzalloc(&s.q_a, g.NqAlloc, stream));
-        DS_CHECK(dzalloc(&s.alpha_a, g.NqAlloc, stream));
-        DS_CHECK(dzalloc(&s.z_a, 10 * g.Nz, stream));
-        DS_CHECK(dzalloc(&s.beta_a, 10 * g.Nz, stream));
+        DS_CHECK(dzalloc(&s.phi_p, g.NphiAlloc, s.st));
+        DS_CHECK(dzalloc(&s.alpha_p, g.NqAlloc, s.st));
+        DS_CHECK(dzalloc(&s.z_p, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.phi_a, g.NphiAlloc, s.st));
+        DS_CHECK(dzalloc(&s.q_a, g.NqAlloc, s.st));
+        DS_CHECK(dzalloc(&s.alpha_a, g.NqAlloc, s.st));
+        DS_CHECK(dzalloc(&s.z_a, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.beta_a, 10 * g.Nz, s.st));
     }
     return 0;
 }
 
 // anchors <- current state (CopyVar, :162,221,356,387)
 int Solver::acc_set_anchors() {
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         const Grid &g = s.g;
         auto cp = [&](double *dst, const double *src, i64 n) {
-            return hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream);
+            return hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s.st);
         };
         DS_HIP(cp(s.phi_a, s.phi, g.NphiAlloc));
         DS_HIP(cp(s.q_a, s.q, g.NqAlloc));
@@ -91,9 +91,9 @@ void Solver::acc_swap_state() {
 // :346-358, called from kkt_block() with the pointers swapped: scale_state() has divided alpha^+, beta^+, c;
 // here the previous iterates follow and the extrapolation restarts from x^+
 int Solver::acc_on_sigma_factor(double factor) {
-    for (auto &s : slabs) {
-        DS_CHECK(launch_scale(s.alpha_p, s.g.NqAlloc, 1.0, factor, stream));
-        DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, stream));
+    FOR_SLABS(s) {
+        DS_CHECK(launch_scale(s.alpha_p, s.g.NqAlloc, 1.0, factor, s.st));
+        DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, s.st));
     }
     acc_k = 0;
     if (acc_halpern) DS_CHECK(acc_set_anchors());
@@ -136,7 +136,7 @@ int Solver::acc_rescale_block() {
     norm_c = norm_c / cScale2;
     if (!prob.weighted) norm_d = norm_d / dScale2;                        // solver_wsocp_accADMM.m has no norm_d
     DS_CHECK(scale_state(dScale2, cScale2 * cScale2, dScale2, true));    // c, alpha, beta, q, z
-    for (auto &s : slabs) DS_CHECK(launch_scale(s.phi, s.g.NphiAlloc, 1.0, dScale2, stream));   // :207
+    FOR_SLABS(s) DS_CHECK(launch_scale(s.phi, s.g.NphiAlloc, 1.0, dScale2, s.st));   // :207
     dScale = dScale2 * dScale;
     cScale = cScale2 * cScale;
     sigmaScale = sigmaScale * (cScale2 / dScale2);
@@ -180,11 +180,11 @@ int Solver::acc_step(bool *brk) {
     // ---- step q (:227-232) ----
     if (!acc_gather_valid) {
         prof_begin(PH_ACC_GATHER);
-        for (auto &s : slabs) {
+        FOR_SLABS(s) {
             AccArgs a{};
             a.z_in = s.z; a.beta_in = s.beta;
             a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
-            DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, stream));
+            DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, s.st));
         }
         prof_end(PH_ACC_GATHER);
     }
@@ -193,15 +193,15 @@ int Solver::acc_step(bool *brk) {
     // q^+ (raw, for the cone pass and the KKT block) always goes to q_old and the right-hand side of the phi-step
     // to w0; without a KKT check the Halpern step of q (in place) and alpha (ping-pong) is part of the same pass
     prof_begin(PH_QSTEP);
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         if (fold) {
             DS_CHECK(launch_qstep_rhs_acc(2, s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.c, s.q_old, s.alpha,
-                                          s.alpha2, s.w0, s.q, s.q_a, s.alpha_a, kc, stream, s.tail_bx, s.tail_by,
+                                          s.alpha2, s.w0, s.q, s.q_a, s.alpha_a, kc, s.st, s.tail_bx, s.tail_by,
                                           s.g.last ? nullptr : s.send_plane));
             std::swap(s.alpha, s.alpha2);
         } else {
             DS_CHECK(launch_qstep_rhs_acc(1, s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.c, s.q_old, s.alpha,
-                                          s.alpha_p, s.w0, nullptr, nullptr, nullptr, kc, stream, s.tail_bx, s.tail_by,
+                                          s.alpha_p, s.w0, nullptr, nullptr, nullptr, kc, s.st, s.tail_bx, s.tail_by,
                                           s.g.last ? nullptr : s.send_plane));
         }
     }
@@ -213,14 +213,14 @@ int Solver::acc_step(bool *brk) {
         DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
         DS_CHECK(group_end());
-        for (auto &s : slabs)
-            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, stream));
+        FOR_SLABS(s)
+            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, s.st));
         prof_end(PH_COMM);
     }
 
     // ---- multipliers + step z (:234-239,246-249); the cone pass does not need phi^+ ----
     prof_begin(PH_ACC_CONE);
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         AccArgs a{};
         a.q = s.q_old;
         a.z_in = s.z; a.beta_in = s.beta;
@@ -230,7 +230,7 @@ int Solver::acc_step(bool *brk) {
             a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
             a.c1 = kc.c1; a.c2 = kc.c2; a.om_rho = kc.om_rho; a.rho = kc.rho;
         }
-        DS_CHECK(launch_acc_cone(fold ? 1 : 0, s.g, lc, s.fg, a, stream));
+        DS_CHECK(launch_acc_cone(fold ? 1 : 0, s.g, lc, s.fg, a, s.st));
     }
     prof_end(PH_ACC_CONE);
 
@@ -260,19 +260,19 @@ int Solver::acc_step(bool *brk) {
     const AccCoef k2 = acc_coef();                         // k may have been reset by the sigma update
     const int mode = acc_halpern ? 0 : (acc_k == 0 ? 1 : 2);
     const int write_aux = (!acc_halpern && acc_k + 1 < acc_restart) ? 1 : 0;      // :417-421
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         const Grid &g = s.g;
-        DS_CHECK(launch_acc_interp(s.phi, s.phi_p, s.phi_a, g.Nphi, k2, mode, write_aux, stream));
+        DS_CHECK(launch_acc_interp(s.phi, s.phi_p, s.phi_a, g.Nphi, k2, mode, write_aux, s.st));
         if (!fold) {
-            DS_CHECK(launch_acc_interp(s.q, s.q_old, s.q_a, g.NqAlloc, k2, mode, write_aux, stream));
-            DS_CHECK(launch_acc_interp(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, mode, write_aux, stream));
+            DS_CHECK(launch_acc_interp(s.q, s.q_old, s.q_a, g.NqAlloc, k2, mode, write_aux, s.st));
+            DS_CHECK(launch_acc_interp(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, mode, write_aux, s.st));
         }
         if (fold) {
             std::swap(s.z, s.z_p);                         // the cone pass wrote the new state there
             std::swap(s.beta, s.beta2);
         } else {
-            DS_CHECK(launch_acc_interp(s.z, s.z_p, s.z_a, 10 * g.Nz, k2, mode, write_aux, stream));
-            DS_CHECK(launch_acc_interp(s.beta, s.beta2, s.beta_a, 10 * g.Nz, k2, mode, write_aux, stream));
+            DS_CHECK(launch_acc_interp(s.z, s.z_p, s.z_a, 10 * g.Nz, k2, mode, write_aux, s.st));
+            DS_CHECK(launch_acc_interp(s.beta, s.beta2, s.beta_a, 10 * g.Nz, k2, mode, write_aux, s.st));
         }
     }
     acc_gather_valid = fold;

@@ -1,35 +1,45 @@
 // Device-side driver steps around the loop: the multilevel transfer
 // jump_nextLevel (+ recoverOrgVar of the coarse level, InitialScaling of the fine one) and the outputs
-// recover_RhoE / recover_q.  Kernels: transfer.hip.  One slab only (time-slab contexts go through the host).
+// recover_RhoE / recover_q.  Kernels: transfer.hip.  The outputs work on time slabs; the level transfer is one-slab.
 #include <cstring>
 
 #include "solver.h"
 
 namespace dotsocp {
 
-// solver_dotsocp2d.m:262-281 on the device; call after finish().  Any output pointer may be NULL.
+// solver_dotsocp2d.m:262-281 on the device; call after finish().  Any output pointer may be NULL.  Time slabs: every
+// slab produces its own layers (the density at its first node needs the left neighbour's last cell: one ny x nx layer
+// to the right); in-process slabs fill the global host arrays, an RCCL rank its own slab of them.
 int Solver::recover_outputs(const double *rho0, const double *rho1, double *rho, double *Ex, double *Ey, double *q0,
                             double *bx, double *by) {
     if (!finished) { set_error("recover_outputs() needs finish()"); return DOTSOCP_ESTATE; }
-    DS_ARG(!multi() && !remote(), "recover_outputs() runs on one slab (download the fields in time-slab mode)");
     DS_ARG(rho == nullptr || (rho0 != nullptr && rho1 != nullptr), "rho needs rho0 and rho1");
-    DS_HIP(hipSetDevice(device));
-    Slab &s = slabs[0];
-    const Grid &g = s.g;
-    const i64 plane = g.plane;
-    double *d_r0 = s.w1, *d_r1 = s.w1 + plane;             // w1 holds at least two layers (nt >= 2)
-    if (rho) {
-        DS_HIP(hipMemcpyAsync(d_r0, rho0, sizeof(double) * plane, hipMemcpyHostToDevice, stream));
-        DS_HIP(hipMemcpyAsync(d_r1, rho1, sizeof(double) * plane, hipMemcpyHostToDevice, stream));
-    }
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
+    const i64 plane = ny * nx;
     const double cD = cScale * D, dD = dScale / D;         // recoverOrgVar (solver_dotsocp2d.m:368-386)
+    if (rho && multi()) {
+        FOR_SLABS(s)
+            if (!s.g.last) DS_CHECK(launch_out_tail(s.g, s.alpha, s.weight, sigma, cD, s.send_plane, s.st));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.a0_prev; }, plane));
+    }
     double *outs[6] = {rho, Ex, Ey, q0, bx, by};
     for (int which = 0; which < 6; ++which) {
         if (!outs[which]) continue;
-        const i64 n = plane * ((which >= 3) ? nt - 1 : nt);
-        DS_CHECK(launch_outputs(g, s.q, s.alpha, s.weight, d_r0, d_r1, sigma, cD, dD, which, s.w0, stream));
-        DS_HIP(hipMemcpyAsync(outs[which], s.w0, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-        DS_HIP(hipStreamSynchronize(stream));
+        FOR_SLABS(s) {
+            const Grid &g = s.g;
+            double *d_r0 = s.w1, *d_r1 = s.w1 + plane;     // w1 holds at least two layers (nt >= 2 per slab)
+            if (which == 0) {
+                if (g.first) DS_HIP(hipMemcpyAsync(d_r0, rho0, sizeof(double) * plane, hipMemcpyHostToDevice, s.st));
+                if (g.last) DS_HIP(hipMemcpyAsync(d_r1, rho1, sizeof(double) * plane, hipMemcpyHostToDevice, s.st));
+            }
+            const i64 layers = (which >= 3) ? g.ncl : g.ntl;
+            DS_CHECK(launch_outputs(g, s.q, s.alpha, s.weight, d_r0, d_r1, s.a0_prev, sigma, cD, dD, which, s.w0, s.st));
+            double *h = outs[which] + (remote() ? 0 : plane * g.t0);
+            if (layers > 0)
+                DS_HIP(hipMemcpyAsync(h, s.w0, sizeof(double) * (size_t)(plane * layers), hipMemcpyDeviceToHost, s.st));
+        }
+        DS_CHECK(sync_all());                               // w0 is reused by the next output
     }
     return 0;
 }
@@ -45,12 +55,15 @@ int Solver::jump_from(Solver &coarse) {
     DS_ARG(ny == 2 * (coarse.ny - 1) + 1 && nt == 2 * (coarse.nt - 1) + 1 &&
                (nx == 2 * (coarse.nx - 1) + 1 || (nx == 1 && coarse.nx == 1)),
            "fine grid must be 2 (n - 1) + 1 of the coarse grid in every dimension");
-    DS_HIP(hipSetDevice(device));
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     DS_CHECK(ensure_alloc());
     Slab &f = slabs[0];
     Slab &c = coarse.slabs[0];
     // everything of the coarse level has to be complete before this level's stream reads it
-    DS_HIP(hipStreamSynchronize(coarse.stream));
+    DS_CHECK(coarse.sync_all());
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
     cScale = prob.cScale; dScale = prob.dScale; D = prob.D; E = prob.E;
     update_coef();
     // phi: dScale_c * phi_c (recoverOrgVar) -> interpolate -> (1/dScale_f) * (InitialScaling)

@@ -32,7 +32,7 @@ int Solver::palm_begin() {
         DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
         prof_end(PH_COMM);
     }
-    for (auto &s : slabs) DS_CHECK(launch_grad(s.g, lc, s.phi, s.q2, stream));
+    FOR_SLABS(s) DS_CHECK(launch_grad(s.g, lc, s.phi, s.q2, s.st));
     if (multi()) {     // ... and BF of that layer the neighbour's first bx / by layers of tmp_q
         prof_begin(PH_COMM);
         DS_CHECK(group_begin());
@@ -40,7 +40,7 @@ int Solver::palm_begin() {
         DS_CHECK(group_end());
         prof_end(PH_COMM);
     }
-    for (auto &s : slabs) DS_CHECK(launch_bfd(s.g, s.z, s.q2, lc.s, lc.dF, stream));
+    FOR_SLABS(s) DS_CHECK(launch_bfd(s.g, s.z, s.q2, lc.s, lc.dF, s.st));
     deferred = false;
     z_valid = true;
     return 0;
@@ -53,13 +53,13 @@ int Solver::palm_step(bool *brk) {
     // ---- first q-step :196-200 ----
     prof_begin(PH_QSTEP0);
     if (deferred) {
-        for (auto &s : slabs) {
+        FOR_SLABS(s) {
             FusedArgs a{};
             a.q_old = s.q_old; a.q = s.q;
             a.beta_in = s.beta; a.beta_out = s.beta2;
             a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
             set_pending(a);
-            DS_CHECK(launch_cone_fused(4, s.g, lc, s.fg, a, stream));
+            DS_CHECK(launch_cone_fused(4, s.g, lc, s.fg, a, s.st));
             std::swap(s.beta, s.beta2);
         }
         bpend = false;
@@ -67,29 +67,29 @@ int Solver::palm_step(bool *brk) {
     } else {
         DS_CHECK(ensure_z());             // first iteration, or right after a KKT / rescale block
         DS_CHECK(flush_beta());
-        for (auto &s : slabs) {
+        FOR_SLABS(s) {
             AccArgs a{};
             a.z_in = s.z; a.beta_in = s.beta;
             a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
-            DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, stream));
+            DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, s.st));
         }
     }
     DS_CHECK(phase_z_tails());            // time slabs: adjoint tails -> right (the phi head travelled in the last iteration)
-    for (auto &s : slabs)
-        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, stream,
+    FOR_SLABS(s)
+        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, s.st,
                                          s.tail_bx, s.tail_by));
     prof_end(PH_QSTEP0);
     if (multi()) {
         // q~ halo -> left (projection of the last cell layer), u0 = q~0 - alpha0 of the last cell -> right (first rhs layer)
         prof_begin(PH_COMM);
-        for (auto &s : slabs)
-            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q_old, s.alpha, nullptr, s.send_plane, stream));
+        FOR_SLABS(s)
+            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q_old, s.alpha, nullptr, s.send_plane, s.st));
         DS_CHECK(group_begin());
         DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
         DS_CHECK(group_end());
-        for (auto &s : slabs)
-            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, stream));
+        FOR_SLABS(s)
+            if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, s.st));
         prof_end(PH_COMM);
     }
     // ---- step phi :202-205 (its right-hand side was formed by the q-step above) ----
@@ -98,12 +98,12 @@ int Solver::palm_step(bool *brk) {
     prof_end(PH_POISSON);
     // ---- step z :207-211 (+ the adjoint sums of :216) ----
     prof_begin(PH_FUSED_A);
-    for (auto &s : slabs) {
+    FOR_SLABS(s) {
         FusedArgs a{};
         a.q = s.q_old;
         a.beta_in = s.beta;
         a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
-        DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, stream));
+        DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, s.st));
     }
     prof_end(PH_FUSED_A);
     z_valid = false;
@@ -111,9 +111,9 @@ int Solver::palm_step(bool *brk) {
     DS_CHECK(phase_z_tails());            // time slabs: phi^{k+1} head -> left, adjoint tails -> right
     // ---- second q-step + alpha :213-218,221,225 ----
     prof_begin(PH_QSTEP);
-    for (auto &s : slabs)
+    FOR_SLABS(s)
         DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, s.tail_bx, s.tail_by, s.q, s.alpha,
-                                    stream));
+                                    s.st));
     prof_end(PH_QSTEP);
     DS_CHECK(exchange_q_halo(false));     // time slabs: q^{k+1} halo (multiplier step, KKT block)
     deferred = true;                       // beta^{k+1}: :222-226, executed by the next pass over beta

@@ -112,8 +112,10 @@ int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t s
 //   which 4: bx  (ny, nx, nt-1)  x-average (0 outside), then t-average                     recover_q.m:15-17
 //   which 5: by  (ny, nx, nt-1)
 // ---------------------------------------------------------------------------------------
+// Time slabs: t below is the slab-local layer, g.t0 + t the global one; the density at a slab's first node
+// averages over the left neighbour's last cell, whose a(.) arrives ready-made in `a_prev` (k_out_tail).
 struct OutArgs {
-    const double *q, *alpha, *weight, *rho0, *rho1;
+    const double *q, *alpha, *weight, *rho0, *rho1, *a_prev;
     double sig, cD, dD;
 };
 
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_outputs(Grid g, OutArgs a, i
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 t = blockIdx.z;
     if (y >= g.ny || x >= g.nx) return;
-    const i64 nt = g.nt;
+    const i64 nt = g.nt, tg = g.t0 + t;
     auto A = [&](i64 k) {
         const double v = a.cD * (a.sig * a.alpha[k]);
         return a.weight ? a.weight[k] * v : v;
@@ -131,11 +133,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_outputs(Grid g, OutArgs a, i
     const i64 node = y + g.ny * (x + g.nx * t);
     double r = 0.0;
     if (which == 0) {
-        if (t == 0) r = a.rho0[y + g.ny * x];
-        else if (t == nt - 1) r = a.rho1[y + g.ny * x];
-        else r = (A(node - g.plane) + A(node)) / 2;
+        if (tg == 0) r = a.rho0[y + g.ny * x];
+        else if (tg == nt - 1) r = a.rho1[y + g.ny * x];
+        else r = ((t == 0 ? a.a_prev[y + g.ny * x] : A(node - g.plane)) + A(node)) / 2;
     } else if (which == 1 || which == 2) {
-        const double f = (t == 0 || t == nt - 1) ? 2.0 : 1.0;
+        const double f = (tg == 0 || tg == nt - 1) ? 2.0 : 1.0;
         if (which == 1) {
             if (x >= 1 && x <= g.nx - 2) {
                 const i64 e = g.offBx + g.bxLayer * t + y + g.ny * x;
@@ -167,10 +169,29 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_outputs(Grid g, OutArgs a, i
     out[node] = r;
 }
 
+// a(.) of the slab's last cell layer, for the density at the right neighbour's first node
+__global__ void __launch_bounds__(256) k_out_tail(Grid g, OutArgs a, double *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.plane) return;
+    const i64 k = i + g.plane * (g.ncl - 1);
+    const double v = a.cD * (a.sig * a.alpha[k]);
+    out[i] = a.weight ? a.weight[k] * v : v;
+}
+
+int launch_out_tail(const Grid &g, const double *alpha, const double *weight, double sig, double cD, double *out,
+                    hipStream_t st) {
+    OutArgs a{nullptr, alpha, weight, nullptr, nullptr, nullptr, sig, cD, 0.0};
+    hipLaunchKernelGGL(k_out_tail, dim3((unsigned)((g.plane + 255) / 256)), dim3(256), 0, st, g, a, out);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_outputs(const Grid &g, const double *q, const double *alpha, const double *weight, const double *rho0,
-                   const double *rho1, double sig, double cD, double dD, int which, double *out, hipStream_t st) {
-    OutArgs a{q, alpha, weight, rho0, rho1, sig, cD, dD};
-    const i64 layers = (which >= 3) ? g.nt - 1 : g.nt;
+                   const double *rho1, const double *a_prev, double sig, double cD, double dD, int which, double *out,
+                   hipStream_t st) {
+    OutArgs a{q, alpha, weight, rho0, rho1, a_prev, sig, cD, dD};
+    const i64 layers = (which >= 3) ? g.ncl : g.ntl;
+    if (layers <= 0) return 0;
     dim3 grid((unsigned)((g.ny + TILE_Y - 1) / TILE_Y), (unsigned)((g.nx + TILE_X - 1) / TILE_X), (unsigned)layers);
     hipLaunchKernelGGL(k_outputs, grid, dim3(TILE_Y, TILE_X), 0, st, g, a, which, out);
     DS_HIP(hipGetLastError());

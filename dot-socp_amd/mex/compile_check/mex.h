@@ -31,6 +31,7 @@ mxArray *mxCreateStructMatrix(size_t m, size_t n, int nfields, const char **fiel
 void mxSetField(mxArray *pa, size_t index, const char *fieldname, mxArray *value);
 int mxGetString(const mxArray *pa, char *buf, size_t buflen);
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...);
+int mexAtExit(void (*fn)(void));
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
 #ifdef __cplusplus
 }

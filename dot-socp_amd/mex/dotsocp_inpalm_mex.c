@@ -7,7 +7,7 @@
  *        phi, q, alpha, z, beta, c, [weight], nx, [ny], nt, D, E, cScale, dScale, normc, normd
  * opts : the options struct of solver_socp_inPALM.m:20-37,64-68 (tau, sigma, maxit, tol,
  *        ifCheckStepByStep required; checkPrimDualFeas, time_limit, scaling optional; device, ngpu
- *        optional extensions).  opts.method (extension, set by the .m wrappers): 'inPALM' (default),
+ *        optional extensions: first device ordinal and number of GPUs, one time slab per GPU).  opts.method (extension, set by the .m wrappers): 'inPALM' (default),
  *        'PALM' (solver_socp_PALM.m) or 'accADMM' (solver_socp_accADMM.m / solver_wsocp_accADMM.m,
  *        which also reads restart, rho, theta, :12-28, and no tau)
  * out  : struct phi, q, z, alpha (= sigma*alpha), beta (= sigma*beta), sigma, cScale, dScale,
@@ -31,10 +31,16 @@ static double opt(const mxArray *s, const char *f, double dflt) {
     return (a && !mxIsEmpty(a)) ? mxGetScalar(a) : dflt;
 }
 
-static mxArray *take(dotsocp_ctx *ctx, int field, const mxArray *like) {
-    mxArray *o = mxCreateDoubleMatrix(mxGetM(like), mxGetN(like), mxREAL);
-    DS_MEX_CHECK(dotsocp_download(ctx, field, mxGetPr(o)), ID);
-    return o;
+/* a full real double array of exactly dotsocp_field_len(p, field) elements, or a MATLAB error (raised before any
+ * pointer reaches the library: upload() reads that many doubles from it) */
+static const double *sized(const mxArray *a, const dotsocp_problem *p, int field, const char *name) {
+    const double *pr = ds_real(a, ID, name);
+    const dotsocp_i64 want = dotsocp_field_len(p, field);
+    if (want < 0) mexErrMsgIdAndTxt(ID ":size", "grid %lld x %lld x %lld is not a valid problem", p->ny, p->nx, p->nt);
+    if ((dotsocp_i64)mxGetNumberOfElements(a) != want)
+        mexErrMsgIdAndTxt(ID ":size", "field '%s' has %lld elements, the %lld x %lld x %lld grid needs %lld", name,
+                          (long long)mxGetNumberOfElements(a), p->ny, p->nx, p->nt, want);
+    return pr;
 }
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
@@ -81,46 +87,70 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     o.scaling = opt(O, "scaling", 0) != 0;
     o.time_limit = opt(O, "time_limit", 3600);
     const int device = (int)opt(O, "device", 0);
-    const int nslabs = (int)opt(O, "ngpu", 1);       /* > 1: time slabs in this process (one device) */
+    /* opts.ngpu > 1: the time axis is cut into that many slabs, slab r on device (device + r) mod #devices of THIS
+     * process (dotsocp_create_multi: streams per slab, peer copies between neighbours) -- MATLAB stays one process */
+    const int ngpu = (int)opt(O, "ngpu", 1);
 
-    dotsocp_ctx *ctx = dotsocp_create(&p, device, nslabs);
-    if (!ctx) mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());
+    /* every array is checked against the grid BEFORE the context exists (nothing to release on these errors) */
     static const char *names[] = {"phi", "q", "alpha", "z", "beta", "c"};
     static const int fields[] = {DOTSOCP_F_PHI, DOTSOCP_F_Q, DOTSOCP_F_ALPHA, DOTSOCP_F_Z, DOTSOCP_F_BETA, DOTSOCP_F_C};
-    int rc = 0;
-    for (int i = 0; i < 6 && rc == 0; ++i) rc = dotsocp_upload(ctx, fields[i], ds_real(need(S, names[i]), ID, names[i]));
-    if (rc == 0 && p.weighted) rc = dotsocp_upload(ctx, DOTSOCP_F_WEIGHT, ds_real(wf, ID, "weight"));
+    const double *in[7];
+    for (int i = 0; i < 6; ++i) in[i] = sized(need(S, names[i]), &p, fields[i], names[i]);
+    in[6] = p.weighted ? sized(wf, &p, DOTSOCP_F_WEIGHT, "weight") : NULL;
+    if (ngpu < 1) mexErrMsgIdAndTxt(ID, "opts.ngpu must be >= 1");
+
+    dotsocp_ctx *ctx = dotsocp_create_multi(&p, device, ngpu);
+    if (!ctx) mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());
+    /* outputs are sized from the grid, not from the inputs' dims (download() writes field_len doubles) */
+    const size_t K = p.dim == 2 ? 10 : 6;
+    const size_t Nphi = (size_t)dotsocp_field_len(&p, DOTSOCP_F_PHI), Nq = (size_t)dotsocp_field_len(&p, DOTSOCP_F_Q);
+    const size_t Nz = (size_t)dotsocp_field_len(&p, DOTSOCP_F_Z) / K;
+    static const char *outf[] = {"phi", "q", "z", "alpha", "beta", "sigma", "cScale", "dScale", "times",
+                                 "kkt", "time", "iter", "pdGap", "time_extra"};
+    static const int ofield[] = {DOTSOCP_F_PHI, DOTSOCP_F_Q, DOTSOCP_F_Z, DOTSOCP_F_ALPHA, DOTSOCP_F_BETA};
+    const size_t om[] = {Nphi, Nq, Nz, Nq, Nz}, on[] = {1, 1, K, 1, K};
+    mxArray *out = mxCreateStructMatrix(1, 1, 14, outf);
     dotsocp_result res;
+    memset(&res, 0, sizeof res);
+    /* var.time carries the reference's tic/toc columns (solver_socp_inPALM.m:339-341): per-step device times on */
+    int rc = dotsocp_set_profiling(ctx, 1);
+    for (int i = 0; i < 6 && rc == 0; ++i) rc = dotsocp_upload(ctx, fields[i], in[i]);
+    if (rc == 0 && p.weighted) rc = dotsocp_upload(ctx, DOTSOCP_F_WEIGHT, in[6]);
     if (rc == 0) rc = dotsocp_begin_method(ctx, &o, method, &acc);
     if (rc == 0) rc = dotsocp_run(ctx, -1, NULL);
     if (rc == 0) rc = dotsocp_finish(ctx, &res);
-    if (rc != 0) {
-        dotsocp_destroy(ctx);                       /* device state is freed before the error is raised */
-        mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());
+    for (int i = 0; i < 5 && rc == 0; ++i) {
+        mxArray *a = mxCreateDoubleMatrix(om[i], on[i], mxREAL);
+        mxSetField(out, 0, outf[i], a);
+        rc = dotsocp_download(ctx, ofield[i], mxGetPr(a));
     }
-    static const char *outf[] = {"phi", "q", "z", "alpha", "beta", "sigma", "cScale", "dScale", "times",
-                                 "kkt", "time", "iter", "pdGap", "time_extra"};
-    mxArray *out = mxCreateStructMatrix(1, 1, 14, outf);
+    mxArray *kkt = NULL, *t = NULL, *it = NULL, *gap = NULL;
+    if (rc == 0) {
+        const size_t n = (size_t)res.hist_len;
+        kkt = mxCreateDoubleMatrix(n, 7, mxREAL); t = mxCreateDoubleMatrix(n, 1, mxREAL);
+        it = mxCreateDoubleMatrix(n, 1, mxREAL); gap = mxCreateDoubleMatrix(n, 1, mxREAL);
+        rc = dotsocp_get_history(ctx, mxGetPr(kkt), mxGetPr(t), mxGetPr(it), mxGetPr(gap));
+    }
+    if (rc != 0) {
+        /* device state is freed before the error is raised (mexErrMsgIdAndTxt does not return; the mxArrays made
+         * so far belong to MATLAB's memory manager and are reclaimed by it) */
+        char msg[1024];
+        strncpy(msg, dotsocp_last_error(), sizeof msg - 1);
+        msg[sizeof msg - 1] = 0;
+        dotsocp_destroy(ctx);
+        mexErrMsgIdAndTxt(ID, "%s", msg);
+    }
+    dotsocp_destroy(ctx);
     mxSetField(out, 0, "time_extra", mxCreateDoubleScalar(res.time_extra));
-    mxSetField(out, 0, "phi", take(ctx, DOTSOCP_F_PHI, need(S, "phi")));
-    mxSetField(out, 0, "q", take(ctx, DOTSOCP_F_Q, need(S, "q")));
-    mxSetField(out, 0, "z", take(ctx, DOTSOCP_F_Z, need(S, "z")));
-    mxSetField(out, 0, "alpha", take(ctx, DOTSOCP_F_ALPHA, need(S, "alpha")));
-    mxSetField(out, 0, "beta", take(ctx, DOTSOCP_F_BETA, need(S, "beta")));
     mxSetField(out, 0, "sigma", mxCreateDoubleScalar(res.sigma));
     mxSetField(out, 0, "cScale", mxCreateDoubleScalar(res.cScale));
     mxSetField(out, 0, "dScale", mxCreateDoubleScalar(res.dScale));
     mxArray *tm = mxCreateDoubleMatrix(1, 7, mxREAL);
     memcpy(mxGetPr(tm), res.times, sizeof res.times);
     mxSetField(out, 0, "times", tm);
-    const size_t n = (size_t)res.hist_len;
-    mxArray *kkt = mxCreateDoubleMatrix(n, 7, mxREAL), *t = mxCreateDoubleMatrix(n, 1, mxREAL);
-    mxArray *it = mxCreateDoubleMatrix(n, 1, mxREAL), *gap = mxCreateDoubleMatrix(n, 1, mxREAL);
-    DS_MEX_CHECK(dotsocp_get_history(ctx, mxGetPr(kkt), mxGetPr(t), mxGetPr(it), mxGetPr(gap)), ID);
     mxSetField(out, 0, "kkt", kkt);
     mxSetField(out, 0, "time", t);
     mxSetField(out, 0, "iter", it);
     mxSetField(out, 0, "pdGap", gap);
-    dotsocp_destroy(ctx);
     plhs[0] = out;
 }

@@ -12,8 +12,8 @@
  *   o   = dotsocp_level_mex('outputs', h, rho0, rho1)     rho, Ex, Ey, q0, bx, by (1-D: rho, Ex, q0, bx)   (:262-281)
  *         dotsocp_level_mex('destroy', h)
  *
- * Handles are small positive integers (doubles) into a table of this MEX file; 'destroy' (or clearing the MEX file)
- * releases the device memory. */
+ * Handles are small positive integers (doubles) into a table of this MEX file; 'destroy' releases the device memory
+ * of one level, and clearing the MEX file (`clear mex`, MATLAB exit) releases every level still open (mexAtExit). */
 #include <string.h>
 
 #include "mex_common.h"
@@ -31,6 +31,24 @@ typedef struct {
 } level_t;
 
 static level_t g_levels[MAXH];
+static int g_atexit = 0;
+
+static void release_all(void) {           /* mexAtExit: `clear mex` must not strand full-grid HBM allocations */
+    for (int i = 0; i < MAXH; ++i)
+        if (g_levels[i].ctx) { dotsocp_destroy(g_levels[i].ctx); g_levels[i].ctx = NULL; }
+}
+
+/* a full real double array of exactly dotsocp_field_len(p, field) elements, or a MATLAB error -- checked before the
+ * level's context exists, so there is nothing to release */
+static const double *sized(const mxArray *a, const dotsocp_problem *p, int field, const char *name) {
+    const double *pr = ds_real(a, ID, name);
+    const dotsocp_i64 want = dotsocp_field_len(p, field);
+    if (want < 0) mexErrMsgIdAndTxt(ID ":size", "grid %lld x %lld x %lld is not a valid problem", p->ny, p->nx, p->nt);
+    if ((dotsocp_i64)mxGetNumberOfElements(a) != want)
+        mexErrMsgIdAndTxt(ID ":size", "field '%s' has %lld elements, the %lld x %lld x %lld grid needs %lld", name,
+                          (long long)mxGetNumberOfElements(a), p->ny, p->nx, p->nt, want);
+    return pr;
+}
 
 static const mxArray *need(const mxArray *s, const char *f) {
     const mxArray *a = mxGetField(s, 0, f);
@@ -61,6 +79,7 @@ static void cmd_create(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[
     if (nrhs < 3 || nrhs > 4 || !mxIsStruct(prhs[1]) || !mxIsStruct(prhs[2]) || nlhs > 1)
         mexErrMsgIdAndTxt(ID, "usage: h = dotsocp_level_mex('create', S, opts[, hCoarse])");
     const mxArray *S = prhs[1], *O = prhs[2];
+    if (!g_atexit) { mexAtExit(release_all); g_atexit = 1; }
     int slot = -1;
     for (int i = 0; i < MAXH && slot < 0; ++i)
         if (!g_levels[i].ctx) slot = i;
@@ -101,19 +120,27 @@ static void cmd_create(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[
     L->o.scaling = opt(O, "scaling", 0) != 0;
     L->o.time_limit = opt(O, "time_limit", 3600);
     level_t *coarse = (nrhs == 4) ? level(prhs[3]) : NULL;
+    /* all arrays are checked against the grid before the context exists */
+    static const char *names[] = {"phi", "q", "alpha", "z", "beta"};
+    static const int fields[] = {DOTSOCP_F_PHI, DOTSOCP_F_Q, DOTSOCP_F_ALPHA, DOTSOCP_F_Z, DOTSOCP_F_BETA};
+    const double *st[5] = {NULL, NULL, NULL, NULL, NULL};
+    const double *cvec = sized(need(S, "c"), &L->p, DOTSOCP_F_C, "c");
+    const double *wvec = L->p.weighted ? sized(wf, &L->p, DOTSOCP_F_WEIGHT, "weight") : NULL;
+    if (!coarse)
+        for (int i = 0; i < 5; ++i) {
+            const mxArray *a = mxGetField(S, 0, names[i]);
+            if (a && !mxIsEmpty(a)) st[i] = sized(a, &L->p, fields[i], names[i]);
+        }
     L->ctx = dotsocp_create(&L->p, (int)opt(O, "device", 0), 1);
     if (!L->ctx) mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());
-    if (dotsocp_upload(L->ctx, DOTSOCP_F_C, ds_real(need(S, "c"), ID, "c")) != 0) fail(L);
-    if (L->p.weighted && dotsocp_upload(L->ctx, DOTSOCP_F_WEIGHT, ds_real(wf, ID, "weight")) != 0) fail(L);
+    if (dotsocp_set_profiling(L->ctx, 1) != 0) fail(L);        /* var.time columns (solver_socp_inPALM.m:339-341) */
+    if (dotsocp_upload(L->ctx, DOTSOCP_F_C, cvec) != 0) fail(L);
+    if (wvec && dotsocp_upload(L->ctx, DOTSOCP_F_WEIGHT, wvec) != 0) fail(L);
     if (coarse) {
         if (dotsocp_jump_next_level(coarse->ctx, L->ctx) != 0) fail(L);
     } else {
-        static const char *names[] = {"phi", "q", "alpha", "z", "beta"};
-        static const int fields[] = {DOTSOCP_F_PHI, DOTSOCP_F_Q, DOTSOCP_F_ALPHA, DOTSOCP_F_Z, DOTSOCP_F_BETA};
-        for (int i = 0; i < 5; ++i) {
-            const mxArray *a = mxGetField(S, 0, names[i]);
-            if (a && !mxIsEmpty(a) && dotsocp_upload(L->ctx, fields[i], ds_real(a, ID, names[i])) != 0) fail(L);
-        }
+        for (int i = 0; i < 5; ++i)
+            if (st[i] && dotsocp_upload(L->ctx, fields[i], st[i]) != 0) fail(L);
     }
     plhs[0] = mxCreateDoubleScalar((double)(slot + 1));
 }

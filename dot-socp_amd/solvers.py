@@ -46,12 +46,14 @@ class InPALMContext:
     """Stateful handle on one device-resident loop (create -> upload -> begin -> run* -> finish)."""
 
     def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False, rccl=None,
-                 method="inPALM", warm_from=None):
+                 method="inPALM", warm_from=None, ngpu=None):
         """rccl = (unique_id_bytes, rank, world): one process per GPU, this process owns time slab
         `rank`; var / model then hold the LOCAL slab of every field (model.nt stays the global nt).
         method: which loop file of the reference runs ("inPALM"/"ALG2" by opts.tau, "PALM", "acc-ADMM").
         warm_from: the finished context of the previous (coarser) multilevel level: phi, q, alpha, z, beta are
-        then produced on the device by jump_nextLevel.m's transfer instead of being uploaded from `var`."""
+        then produced on the device by jump_nextLevel.m's transfer instead of being uploaded from `var`.
+        ngpu: single-process multi-GPU (dotsocp_create_multi): that many time slabs, slab r on device
+        (device + r) mod #devices; nslabs (diagnostic) keeps all slabs on `device`."""
         L = capi.lib()
         self.method = method
         one_d = not hasattr(model, "ny")
@@ -63,7 +65,10 @@ class InPALMContext:
         p.D, p.E, p.cScale, p.dScale = float(var.D), float(var.E), float(var.cScale), float(var.dScale)
         p.normc, p.normd = float(model.normc), float(model.normd)
         self.var, self.model, self.weighted = var, model, weighted
-        self._ctx = L.dotsocp_create(ctypes.byref(p), int(device), int(nslabs))
+        if ngpu is not None and int(ngpu) > 1:
+            self._ctx = L.dotsocp_create_multi(ctypes.byref(p), int(device), int(ngpu))
+        else:
+            self._ctx = L.dotsocp_create(ctypes.byref(p), int(device), int(nslabs))
         if not self._ctx:
             raise capi.DotsocpError(-1, L.dotsocp_last_error().decode())
         try:

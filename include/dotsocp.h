@@ -165,12 +165,19 @@ typedef struct {
     double time_extra;     /* acc-ADMM: 'Interp' (solver_socp_accADMM.m:438-439); PALM: 'Step_1_Q_Step' */
 } dotsocp_result;
 
-/* `device` = HIP device ordinal.  `nslabs` >= 1 splits the time axis into that many
- * slabs that live in this one process (the multi-GPU algorithm -- halo exchange and the
- * slab<->pencil transposes of the Poisson solve -- executed with device-to-device
- * copies); production multi-GPU runs use one process per GPU, nslabs = 1 and a
- * communicator attached with dotsocp_attach_rccl(). */
+/* `device` = HIP device ordinal.  `nslabs` >= 1 splits the time axis into that many slabs that live in this one
+ * process ON THAT ONE DEVICE (the multi-GPU algorithm -- halo exchange and the t-axis coupling of the Poisson
+ * solve -- with every slab on its own pair of streams and device-to-device copies as messages): a rehearsal /
+ * diagnostic mode.  Multi-GPU runs use either
+ *   - dotsocp_create_multi(): ONE process, slab r on device (first_device + r) mod #visible devices, neighbour layers
+ *     and the interface values of the t-solve travel as peer copies (hipMemcpyPeerAsync over xGMI), per-device KKT
+ *     partial sums are added up on the host.  This is what a single MATLAB process (solver_dotsocp2d.m:208 calls
+ *     the loop synchronously from the interpreter thread) uses: opts.ngpu of the MEX gateway.  With fewer devices
+ *     than slabs, slabs share devices (one device: same as dotsocp_create(prob, device, ngpu)).  upload / download /
+ *     recover_outputs take and return the GLOBAL fields, exactly as with one slab; or
+ *   - one process per GPU: dotsocp_create(prob, device, 1) + dotsocp_attach_rccl() (bench.py, torch.distributed). */
 dotsocp_ctx *dotsocp_create(const dotsocp_problem *prob, int device, int nslabs);
+dotsocp_ctx *dotsocp_create_multi(const dotsocp_problem *prob, int first_device, int ngpu);
 void dotsocp_destroy(dotsocp_ctx *ctx);
 
 /* One process per GPU: this process owns time slab `rank` of `world`.  `unique_id` is the
@@ -185,6 +192,12 @@ int dotsocp_attach_rccl(dotsocp_ctx *ctx, const unsigned char id[128], int rank,
  * nodes [*t0, *t1) of the nt time nodes belong to slab `rank`; its staggered cells are
  * [*t0, min(*t1, nt-1)). */
 int dotsocp_slab_range(dotsocp_i64 nt, int world, int rank, dotsocp_i64 *t0, dotsocp_i64 *t1);
+
+/* Number of doubles of the GLOBAL field `field` (DOTSOCP_F_*) of problem `prob` in the reference layout -- what
+ * upload() reads and download() writes for a context without an RCCL communicator.  Pure host arithmetic (no
+ * device); -1 for an unknown field or a grid with nt < 2.  The MEX gateways check their mxArrays against it
+ * before any pointer reaches the library. */
+dotsocp_i64 dotsocp_field_len(const dotsocp_problem *prob, int field);
 
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host);
 int dotsocp_download(dotsocp_ctx *ctx, int field, double *host);
@@ -207,7 +220,9 @@ int dotsocp_finish(dotsocp_ctx *ctx, dotsocp_result *res);
  * (utils/recover_q.m:12-22) from the device-resident alpha and q, so that only the outputs cross PCIe.  Call
  * after finish().  rho0, rho1: model.rho0 / rho1 (ny x nx, host).  Outputs (host, column-major, any may be NULL):
  * rho, Ex, Ey: ny x nx x nt;  q0, bx, by: ny x nx x (nt-1).  1-D problems: rho, Ex: nx x nt; q0, bx: nx x (nt-1);
- * Ey, by ignored.  One-slab contexts only (DOTSOCP_EINVAL otherwise). */
+ * Ey, by ignored.  Works on time slabs too: in-process slabs (nslabs / dotsocp_create_multi) fill the global arrays;
+ * with an RCCL communicator attached every rank gets its own slab of them (node layers [t0, t1) of rho, Ex, Ey,
+ * cell layers of q0, bx, by; rho0 / rho1 are read on the first / last rank only). */
 int dotsocp_recover_outputs(dotsocp_ctx *ctx, const double *rho0, const double *rho1, double *rho, double *Ex,
                             double *Ey, double *q0, double *bx, double *by);
 
@@ -221,10 +236,13 @@ int dotsocp_jump_next_level(dotsocp_ctx *coarse, dotsocp_ctx *fine);
 /* runHist.{kkt (len x 7, column-major), time, iter, pdGap} (:350-354); any pointer may be NULL */
 int dotsocp_get_history(dotsocp_ctx *ctx, double *kkt, double *time, double *iter, double *pdGap);
 
-/* Diagnostics for bench.py: average device time in ms of the named kernel family over
- * the launches since begin() (HIP events on the launch stream), and its launch count.
- * names: "cone_proj", "beta", "qstep", "rhs", "poisson", "kkt". Profiling must be enabled
- * with dotsocp_set_profiling(ctx, 1) before begin(). */
+/* Per-step device times (HIP events on the launch stream): feeds result.times[0..4] (the reference's tic/toc
+ * columns Step_1_1_FFT .. KKT, solver_socp_inPALM.m:339-341) and dotsocp_kernel_time().  Off by default; may be
+ * switched at any time outside run() -- before begin() to cover the whole solve (the MEX gateways do that), or
+ * between two run() calls to cover only what follows (bench.py switches it on after its warm-up iterations).
+ * dotsocp_kernel_time: average device time in ms of the named kernel family over the profiled launches since
+ * begin(), and their count; names: "rhs", "poisson", "cone_proj", "qstep", "beta", "kkt", "cone_fused_a",
+ * "cone_fused_b", "materialise", "comm", "interp", "acc_cone", "acc_gather", "qstep_first", "transpose". */
 int dotsocp_set_profiling(dotsocp_ctx *ctx, int on);
 int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dotsocp_i64 *launches);
 

@@ -92,6 +92,20 @@ void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...) {
     abort();
 }
 
+/* exit handlers run when the harness "clears" the MEX file (fmx_clear_mex) */
+static void (*g_exit_fn[8])(void);
+static int g_exit_n = 0;
+
+int mexAtExit(void (*fn)(void)) {
+    if (g_exit_n < 8) g_exit_fn[g_exit_n++] = fn;
+    return 0;
+}
+
+void fmx_clear_mex(void) {
+    for (int i = 0; i < g_exit_n; ++i) g_exit_fn[i]();
+    g_exit_n = 0;
+}
+
 /* ---- harness side ---- */
 mxArray *fmx_wrap_double(size_t m, size_t n, double *data) {       /* aliases the caller's memory (in-place gateways) */
     mxArray *a = (mxArray *)calloc(1, sizeof *a);

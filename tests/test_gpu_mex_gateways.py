@@ -33,7 +33,7 @@ def mx():
     for name, res, args in [("fmx_wrap_double", vp, [ctypes.c_size_t, ctypes.c_size_t, vp]),
                             ("fmx_string", vp, [ctypes.c_char_p]),
                             ("fmx_struct", vp, [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]),
-                            ("fmx_free", None, [vp]),
+                            ("fmx_free", None, [vp]), ("fmx_clear_mex", None, []),
                             ("fmx_call", ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp)]),
                             ("fmx_error_id", ctypes.c_char_p, []), ("fmx_error_msg", ctypes.c_char_p, []),
                             ("mxCreateDoubleScalar", vp, [ctypes.c_double]),
@@ -212,13 +212,69 @@ def test_solver_gateway_matches_the_python_binding(mx, method, weighted):
     np.testing.assert_array_equal(_field(L, out, "kkt"), hist["kkt"])
     np.testing.assert_array_equal(_field(L, out, "iter").ravel(), hist["iter"])
     assert float(_field(L, out, "cScale")[0, 0]) == var.cScale and float(_field(L, out, "dScale")[0, 0]) == var.dScale
-    assert _field(L, out, "times").shape == (1, 7)
+    # var.time (solver_socp_inPALM.m:339-341): the five step columns are device times, filled and consistent
+    tm = _field(L, out, "times")
+    assert tm.shape == (1, 7) and tm[0, 6] == K
+    steps = tm[0, :5]
+    nonzero = steps > 0
+    assert nonzero[0] and nonzero[2] and nonzero[4], steps            # FFT, q-step, KKT ran in every loop variant
+    assert nonzero[1] or method == "accADMM"                          # acc-ADMM books its cone pass as Step_3_2
+    assert 0 < steps.sum() <= tm[0, 5] * 1.05 + 1e-3, (steps, tm[0, 5])   # device time inside the host wall time
     L.fmx_free(out)
     # a missing required field is a MATLAB error, not a crash
     bad = dict(opts)
     del bad["sigma"]
     err, _ = Call(L).run(g["dotsocp_inpalm_mex"], [S, bad], nlhs=1)
     assert err and err[0] == "dotsocp:inPALM" and "sigma" in err[1]
+    # an array whose length disagrees with nx, ny, nt is refused before any pointer reaches the library
+    for name in ("q", "beta", "c"):
+        short = dict(S)
+        short[name] = np.asfortranarray(np.asarray(S[name]).ravel(order="F")[:-3].copy())
+        err, _ = Call(L).run(g["dotsocp_inpalm_mex"], [short, opts], nlhs=1)
+        assert err and err[0] == "dotsocp:inPALM:size" and name in err[1], err
+    if weighted:
+        short = dict(S)
+        short["weight"] = S["weight"][:-1].copy()
+        err, _ = Call(L).run(g["dotsocp_inpalm_mex"], [short, opts], nlhs=1)
+        assert err and err[0] == "dotsocp:inPALM:size" and "weight" in err[1], err
+
+
+def test_solver_gateway_ngpu_is_the_single_process_multi_device_mode(mx):
+    """opts.ngpu = N: N time slabs, slab r on device r mod #devices of this ONE process (dotsocp_create_multi), as a
+    MATLAB host would drive several GPUs; on the one-GPU test box all slabs share the device.  The result must agree
+    with ngpu = 1 to the slab tolerance and carry the same history."""
+    L, g = mx
+    rho0, rho1 = get_example_2d("example1", 24, 16)
+    nt, K = 16, 20
+    o = OD.default_opts(dict(tol=0.0, maxit=K), "inPALM", False)
+    var, model = D.initialize(rho0, rho1, nt)
+    D.InitialScaling(var, model, True, None, dim=2)
+
+    def run(ngpu):
+        S = dict(phi=var.phi.copy(), q=var.q.copy(), alpha=var.alpha.copy(), z=var.z.copy(order="F"),
+                 beta=var.beta.copy(order="F"), c=model.c.copy(), nx=model.nx, ny=model.ny, nt=model.nt, D=var.D, E=var.E,
+                 cScale=var.cScale, dScale=var.dScale, normc=model.normc, normd=model.normd)
+        opts = dict(sigma=o["sigma"], maxit=K, tol=0.0, ifCheckStepByStep=0.0, scaling=1.0, tau=o["tau"], ngpu=float(ngpu))
+        err, outs = Call(L).run(g["dotsocp_inpalm_mex"], [S, opts], nlhs=1)
+        assert err is None, err
+        res = {f: _field(L, outs[0], f) for f in ("phi", "q", "z", "alpha", "beta", "kkt", "iter", "times", "sigma")}
+        L.fmx_free(outs[0])
+        return res
+
+    one, four = run(1), run(4)
+    np.testing.assert_array_equal(four["iter"], one["iter"])
+    np.testing.assert_allclose(four["kkt"], one["kkt"], rtol=1e-7, atol=1e-10)
+    assert abs(four["sigma"][0, 0] - one["sigma"][0, 0]) <= 1e-12 * one["sigma"][0, 0]
+    for f in ("phi", "q", "z", "alpha", "beta"):
+        err = np.max(np.abs(four[f] - one[f])) / np.max(np.abs(one[f]))
+        assert err <= 1e-10, (f, err)
+    assert four["times"][0, 0] > 0 and four["times"][0, 6] == K
+    bad = dict(sigma=1.0, maxit=K, tol=0.0, ifCheckStepByStep=0.0, scaling=1.0, tau=1.9, ngpu=0.0)
+    S = dict(phi=var.phi.copy(), q=var.q.copy(), alpha=var.alpha.copy(), z=var.z.copy(order="F"), beta=var.beta.copy(order="F"),
+             c=model.c.copy(), nx=model.nx, ny=model.ny, nt=model.nt, D=var.D, E=var.E, cScale=var.cScale, dScale=var.dScale,
+             normc=model.normc, normd=model.normd)
+    err, _ = Call(L).run(g["dotsocp_inpalm_mex"], [S, bad], nlhs=1)
+    assert err and "ngpu" in err[1]
 
 
 def test_level_gateway_runs_the_multilevel_driver_on_the_device(mx):
@@ -289,3 +345,16 @@ def test_level_gateway_runs_the_multilevel_driver_on_the_device(mx):
     # a stale handle is an error, not a crash
     err, _ = Call(L).run(gate, ["solve", h2], nlhs=1)
     assert err and err[0] == "dotsocp:level"
+    # a length that disagrees with the grid is refused before the level exists
+    var, model = D.initialize(r0c, r1c, ntc, lazy_zeros=True)
+    D.InitialScaling(var, model, True, None, dim=2)
+    S = level_struct(var, model)
+    S["c"] = S["c"][:-1].copy()
+    err, _ = Call(L).run(gate, ["create", S, mopts(o, tolc)], nlhs=1)
+    assert err and err[0] == "dotsocp:level:size" and "'c'" in err[1], err
+    # `clear mex` with a level still open: the exit handler releases its device memory, the handle dies with it
+    S = level_struct(var, model)
+    h3 = Mx(call("create", S, mopts(o, tolc)))
+    L.fmx_clear_mex()
+    err, _ = Call(L).run(gate, ["solve", h3], nlhs=1)
+    assert err and err[0] == "dotsocp:level" and "invalid level handle" in err[1]

@@ -1,0 +1,115 @@
+"""Single-process multi-device mode (dotsocp_create_multi / opts.ngpu of the MEX gateway): the one MATLAB process of
+solver_dotsocp2d.m:208 driving several GPUs.  Every time slab has its own device, its own pair of streams and
+event-ordered peer copies to its neighbours.  The test box has ONE GPU, so slab r's device is (0 + r) mod 1 = 0 for
+every slab: what is exercised here is everything but the physical link -- per-slab streams running concurrently,
+the event ordering of every cross-slab copy (a missing dependency shows up as a wrong or irreproducible result),
+the host-side reduction of the per-slab KKT sums, global upload / download / outputs.  Checked against the
+single-slab run of the same problem, for all three loops."""
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from oracle import driver as OD
+from oracle.examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, get_example_1d,
+                             get_example_2d, get_weight_by_barrier)
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("phi", "q", "z", "alpha", "beta")
+
+
+def _relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _run(rho0, rho1, nt, opts, method, weight=None, outputs=False, **kw):
+    dim = 2 if np.ndim(rho0) == 2 else 1
+    var, model = D.initialize(rho0, rho1, nt)
+    if weight is not None:
+        model.weight = np.asarray(weight, dtype=np.float64)
+    o = OD.default_opts(opts, method, weight is not None)
+    D.InitialScaling(var, model, o["scaling"], None, dim=dim, weighted=weight is not None)
+    ctx = D.InPALMContext(var, o, model, weighted=weight is not None, method=method, **kw)
+    ctx.run(-1)
+    hist, sigma = ctx.finish(download=True)
+    outs = ctx.outputs() if outputs else None
+    ctx.close()
+    return var, model, hist, sigma, outs
+
+
+@pytest.mark.parametrize("method,ngpu,ny,nx,nt,K", [
+    ("inPALM", 2, 32, 24, 16, 30), ("inPALM", 3, 40, 36, 48, 30), ("inPALM", 4, 64, 64, 64, 25),
+    ("inPALM", 8, 32, 32, 128, 20), ("ALG2", 2, 33, 17, 9, 20), ("PALM", 2, 32, 24, 16, 25), ("PALM", 3, 24, 40, 48, 20),
+    ("acc-ADMM", 2, 32, 24, 16, 25), ("acc-ADMM", 4, 32, 32, 64, 20)])
+def test_multi_device_matches_single_slab(method, ngpu, ny, nx, nt, K):
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    opts = dict(tol=0.0, maxit=K)
+    ref, _, h1, s1, _ = _run(rho0, rho1, nt, opts, method)
+    got, _, hn, sn, _ = _run(rho0, rho1, nt, opts, method, ngpu=ngpu)
+    np.testing.assert_array_equal(hn["iter"], h1["iter"])
+    np.testing.assert_allclose(hn["kkt"], h1["kkt"], rtol=1e-7, atol=1e-10)
+    assert abs(sn - s1) <= 1e-12 * s1
+    errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-10, errs
+    # several streams run concurrently: a race would make two runs differ
+    again, _, ha, sa, _ = _run(rho0, rho1, nt, opts, method, ngpu=ngpu)
+    assert sa == sn and np.array_equal(ha["kkt"], hn["kkt"])
+    for f in FIELDS:
+        assert np.array_equal(getattr(again, f), getattr(got, f)), f
+
+
+@pytest.mark.parametrize("tsolve", ["tridiag", "dct"])
+def test_multi_device_both_t_solves_weighted_and_1d(tsolve, monkeypatch):
+    monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    barrier = gene_barrier_of_circle_pillar()
+    weight = get_weight_by_barrier(32, 32, 16, barrier)
+    rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    opts = dict(tol=0.0, maxit=25)
+    ref, _, h1, s1, _ = _run(rho0, rho1, 16, opts, "inPALM", weight)
+    got, _, hn, sn, _ = _run(rho0, rho1, 16, opts, "inPALM", weight, ngpu=3)
+    np.testing.assert_array_equal(hn["iter"], h1["iter"])
+    errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-8, errs
+    r0, r1 = get_example_1d("gaussian", 128)
+    ref, _, h1, s1, _ = _run(r0, r1, 32, dict(tol=0.0, maxit=40), "inPALM")
+    got, _, hn, sn, _ = _run(r0, r1, 32, dict(tol=0.0, maxit=40), "inPALM", ngpu=4)
+    np.testing.assert_array_equal(hn["iter"], h1["iter"])
+    errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-10, errs
+
+
+@pytest.mark.parametrize("case,ngpu", [("dot2d", 3), ("wdot2d", 2), ("dot1d", 4)])
+def test_outputs_on_time_slabs_equal_host_recovery(case, ngpu):
+    """dotsocp_recover_outputs on a multi-slab context (the density at a slab's first node averages over the left
+    neighbour's last cell) against recoverOrgVar + recover_RhoE + recover_q of the iterates downloaded from the same
+    context: same arithmetic in the same order -> identical."""
+    weight = None
+    if case == "dot1d":
+        rho0, rho1 = get_example_1d("gaussian", 65)
+        nt, dim = 17, 1
+    else:
+        rho0, rho1 = get_example_2d("example1", 24, 40)
+        nt, dim = 12, 2
+        if case == "wdot2d":
+            barrier = gene_barrier_of_circle_pillar()
+            weight = get_weight_by_barrier(40, 24, nt, barrier)
+            rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    var, model, hist, sigma, dev = _run(rho0, rho1, nt, dict(tol=0.0, maxit=30), "inPALM", weight, outputs=True, ngpu=ngpu)
+    D.recoverOrgVar(var)
+    rE = D.recover_RhoE(var, model, weighted=weight is not None)
+    rq = D.recover_q(var, model)
+    names = ("rho", "Ex", "q0", "bx") if dim == 1 else ("rho", "Ex", "Ey", "q0", "bx", "by")
+    host = dict(zip(names, (rE + rq) if dim == 2 else (rE[0], rE[1], rq[0], rq[1])))
+    for k in names:
+        assert dev[k].shape == host[k].shape, k
+        np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
+
+
+def test_free_running_multi_device_against_oracle():
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    ovar, omodel, o_hist, o_sigma = OD.solve_single_level(rho0, rho1, 16, dict(tol=1e-4))
+    var, _, hist, sigma, _ = _run(rho0, rho1, 16, dict(tol=1e-4), "inPALM", ngpu=4)
+    assert hist["iter"][-1] == o_hist["iter"][-1]
+    D.recoverOrgVar(var)
+    errs = {f: _relerr(getattr(var, f), getattr(ovar, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-7, errs

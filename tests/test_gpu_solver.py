@@ -70,7 +70,7 @@ def test_trajectory_dot2d(n, nt, K):
     _compare_run(rho0, rho1, nt, dict(tol=0.0), K)
 
 
-@pytest.mark.parametrize("n,nt,K", [(256, 64, 50), (257, 65, 20)])
+@pytest.mark.parametrize("n,nt,K", [(256, 64, 50), (257, 65, 50)])
 def test_parity_gate_config2(n, nt, K, request):
     """SURVEY.md section 8d parity gate: BASELINE config 2 (256x256x64) and its multilevel-compatible
     2^k+1 twin, K iterations with the live sigma / rescale schedule, all five state arrays <= 1e-9.
