@@ -83,6 +83,7 @@ SYMBOLS = {
     "dotsocp_get_history": (ctypes.c_int, [vp, vp, vp, vp, vp]),
     "dotsocp_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),
     "dotsocp_kernel_time": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.POINTER(dbl), ctypes.POINTER(i64)]),
+    "dotsocp_canary_check": (ctypes.c_int, []),
     "dotsocp_synchronize": (ctypes.c_int, [vp]),
 }
 

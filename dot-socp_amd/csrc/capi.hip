@@ -356,6 +356,13 @@ int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dots
     return DOTSOCP_EINVAL;
 }
 
+int dotsocp_canary_check(void) {
+    std::string rep;
+    const int bad = canary_check(&rep);
+    if (bad) set_error("canary: %d device buffer(s) written out of bounds: %s", bad, rep.c_str());
+    return bad;
+}
+
 int dotsocp_synchronize(dotsocp_ctx *ctx) {
     CTX_OR_FAIL();
     ctx->s.cur_dev = -1;

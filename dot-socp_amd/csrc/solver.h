@@ -9,12 +9,22 @@
 
 namespace dotsocp {
 
+// Device allocations of the solver state go through guard.hip: with DOTSOCP_CANARY=1 in the environment every buffer
+// gets a guard band of NaN-pattern words on both sides, checked by canary_check() (finish(), destroy()) -- an
+// out-of-bounds WRITE of a tile kernel on a partial tile changes a guard word, an out-of-bounds READ pulls NaNs
+// into the iterates.  Without the variable the calls are plain hipMalloc / hipFree.
+int guarded_malloc(void **p, size_t bytes);
+void guarded_free(void *p);
+// number of live buffers whose guard bands were overwritten (0 when the canaries are off); `report` receives a
+// description of the first few.  Synchronises the current device.
+int canary_check(std::string *report);
+bool canary_enabled();
+
 template <class T>
 inline int dmalloc(T **p, i64 n) {
     *p = nullptr;
     if (n <= 0) n = 1;
-    DS_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)n));
-    return 0;
+    return guarded_malloc((void **)p, sizeof(T) * (size_t)n);
 }
 
 inline int dzalloc(double **p, i64 n, hipStream_t st) {
@@ -24,7 +34,7 @@ inline int dzalloc(double **p, i64 n, hipStream_t st) {
 }
 
 inline void dfree(void *p) {
-    if (p) (void)hipFree(p);
+    if (p) guarded_free(p);
 }
 
 // Resources that live once per HIP device and are shared by the slabs placed on it.

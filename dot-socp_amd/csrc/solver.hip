@@ -173,6 +173,12 @@ void Solver::free_slabs() {
 Solver::~Solver() {
     cur_dev = -1;
     if (stream) (void)sync_all();   // init() got as far as the device: release what lives there
+    if (stream && canary_enabled()) {
+        std::string rep;
+        const int bad = canary_check(&rep);
+        cur_dev = -1;
+        if (bad) fprintf(stderr, "libdotsocp: canary: %d device buffer(s) written out of bounds: %s\n", bad, rep.c_str());
+    }
     if (nccl) (void)rccl_api().CommDestroy((ncclComm_t)nccl);
     free_slabs();
     for (auto *r : devres) {
@@ -910,6 +916,14 @@ int Solver::begin(const dotsocp_opts *o) {
     rhs_valid = false;
     hist_kkt.clear(); hist_time.clear(); hist_iter.clear(); hist_gap.clear();
     for (int i = 0; i < PH_COUNT; ++i) { phase_ms[i] = 0; phase_launches[i] = 0; }
+    if (canary_enabled() && getenv("DOTSOCP_CANARY_SELFTEST")) {
+        // test hook: one double written right behind model.c, the way a kernel overrunning its last tile would
+        Slab &s0 = slabs[0];
+        DS_CHECK(use(s0));
+        const double v = 1.0;
+        DS_HIP(hipMemcpyAsync(s0.c + s0.g.Nphi, &v, sizeof v, hipMemcpyHostToDevice, s0.st));
+        DS_HIP(hipStreamSynchronize(s0.st));
+    }
     begun = true;
     elapsed_prev = 0.0;
     elapsed_agreed = 0.0;
@@ -1457,6 +1471,15 @@ int Solver::finish(dotsocp_result *res) {
     DS_CHECK(flush_beta());
     DS_CHECK(sync_all());
     DS_CHECK(prof_flush());
+    if (canary_enabled()) {        // DOTSOCP_CANARY=1: no kernel of this solve wrote outside its buffers
+        std::string rep;
+        const int bad = canary_check(&rep);
+        cur_dev = -1;
+        if (bad) {
+            set_error("canary: %d device buffer(s) written out of bounds: %s", bad, rep.c_str());
+            return DOTSOCP_EHIP;
+        }
+    }
     finished = true;
     if (res) {
         memset(res, 0, sizeof *res);

@@ -10,13 +10,13 @@
         if (rc__ != 0) mexErrMsgIdAndTxt(id, "%s", dotsocp_last_error()); \
     } while (0)
 
-static double *ds_real(const mxArray *a, const char *id, const char *what) {
+static inline double *ds_real(const mxArray *a, const char *id, const char *what) {
     if (!mxIsDouble(a) || mxIsComplex(a) || mxIsSparse(a))
         mexErrMsgIdAndTxt(id, "%s must be a full real double array", what);
     return mxGetPr(a);
 }
 
-static double ds_scalar(const mxArray *a, const char *id, const char *what) {
+static inline double ds_scalar(const mxArray *a, const char *id, const char *what) {
     if (!mxIsDouble(a) || mxGetNumberOfElements(a) != 1)
         mexErrMsgIdAndTxt(id, "%s must be a scalar", what);
     return mxGetScalar(a);

@@ -246,6 +246,13 @@ int dotsocp_get_history(dotsocp_ctx *ctx, double *kkt, double *time, double *ite
 int dotsocp_set_profiling(dotsocp_ctx *ctx, int on);
 int dotsocp_kernel_time(dotsocp_ctx *ctx, const char *name, double *avg_ms, dotsocp_i64 *launches);
 
+/* Guard bands (debugging aid): with DOTSOCP_CANARY=1 in the environment every device buffer of
+ * the solver state is allocated between two bands of NaN-pattern words.  dotsocp_finish() fails with DOTSOCP_EHIP if a
+ * band was overwritten (message: which buffer, how many words, where), dotsocp_destroy() reports to stderr, and this
+ * call checks all live buffers of the process at any time: returns the number of damaged buffers (0 = clean, also
+ * when the canaries are off) and sets dotsocp_last_error() accordingly.  An out-of-bounds READ shows up as NaNs. */
+int dotsocp_canary_check(void);
+
 /* Blocks until all work enqueued by this context has completed. */
 int dotsocp_synchronize(dotsocp_ctx *ctx);
 

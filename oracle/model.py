@@ -164,11 +164,17 @@ def mirt_idctn(a):
     return a
 
 
-def oper_poisson(kernel, rhs, fast=True, workers=-1):
+FFT_WORKERS = -1      # threads of scipy's DCT (-1: all cores, like MATLAB's implicitly multithreaded fft); bench.py's
+                      # cpu_baseline leg sets 1 for its single-thread figure
+
+
+def oper_poisson(kernel, rhs, fast=True, workers=None):
     """socp/dot2d/utils/oper_poisson3dim.m:4 and socp/dot1d/utils/oper_poisson.m:4:
     res = idctn(dctn(rhs) ./ kernel).  `rhs` is shaped like `kernel` in Fortran sense.
     fast=True uses scipy's orthonormal DCT-II/III (identical transform, see
     tests/test_oracle_invariants.py::test_mirt_dct_equals_scipy)."""
+    if workers is None:
+        workers = FFT_WORKERS
     if fast:
         return sfft.idctn(sfft.dctn(rhs, norm="ortho", workers=workers) / kernel, norm="ortho", workers=workers)
     return mirt_idctn(mirt_dctn(rhs) / kernel)
