@@ -122,10 +122,23 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
                        const double *tail_bx, const double *tail_by, double *q_out, double *alpha,
                        hipStream_t st);
 // q-step + alpha update (alpha_in -> alpha_out, distinct buffers) + rhs of the next iteration's phi-step
+// ex (optional): a scaling of alpha_in that is still pending in memory (applied on load), and -- partials != nullptr, one
+// slab only -- the KKT variant: the sums of the KKT block that need only phi, q^+, alpha^+, A phi and c are accumulated in
+// the same pass (one row of S_COUNT partial sums per workgroup at `partials`), r = A' alpha^+ - c goes to `resid`
+struct QStepExtra {
+    int apend;
+    double amul, adiv;
+    double *partials, *resid;
+    double kappa, dsD;       // KktCoef
+};
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
-                     double *rhs, hipStream_t st, i64 z0 = 0, i64 zcount = -1, i64 zstride = 1);
+                     double *rhs, hipStream_t st, i64 z0 = 0, i64 zcount = -1, i64 zstride = 1,
+                     const QStepExtra *ex = nullptr);
+i64 qstep_rhs_blocks(const Grid &g, const FusedGeom &fg);
+// rhs <- (rhs + r) - r / factor, c <- c / factor  (sigma update without a new pass over q and alpha)
+int launch_rhs_sigma_fix(double *rhs, const double *r, double *cvec, i64 n, double factor, hipStream_t st);
 // chunks of time layers of that launch (z0 + i * zstride, i < zcount, selects chunks; chunks are independent of each other: only
 // chunk 0 reads the adjoint tails of the left neighbour slab and only the last one the phi halo of the right one)
 i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TC = nullptr);
@@ -194,9 +207,13 @@ int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double 
                const double *alpha, const double *z, const double *beta, const double *cvec,
                const double *weight, const KktHalo &halo, const KktWork &w, int parts, hipStream_t st);
 // fused path: pending multiplier step (beta_in -> beta_out, distinct buffers) + the cell part of the sums
+// edges (one slab, after a q-step in its KKT variant): also the F*B*beta' sums of every edge and the momentum terms of
+// the edges on tile borders (a.q2 / a.sx / a.sy are scratch; q_new = q^{k+1})
 int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, FusedArgs a,
                             const double *phi, const double *alpha, const double *weight, const KktWork &w,
-                            hipStream_t st);
+                            hipStream_t st, bool edges = false, const double *q_new = nullptr);
+// partial sums of the q-step's KKT variant: region 0 of w.partials
+double *kkt_qstep_partials(const Grid &g, const KktWork &w);
 int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st);
 
 // ---------------- dct.hip ----------------

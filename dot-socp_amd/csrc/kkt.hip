@@ -6,6 +6,7 @@
 // with cross-lane shuffles, over the workgroup through LDS, and written as per-block partials;
 // a second kernel adds the partials in a fixed order (deterministic, no atomics).
 #include "device_utils.h"
+#include "gather_tile.h"
 #include "kernels.h"
 
 namespace dotsocp {
@@ -191,97 +192,173 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
 //   of compute_kkt_dot_complement.m:2-9, and the q0 entries' share of the edge sums.
 // t-marching like k_cone_fused; z is not written (MODE_Z of k_cone_fused regenerates it on demand
 // from the kept beta_in).
-template <bool WEIGHTED>
+//
+// EDGES = true (one slab, iterations whose q-step ran in its KKT variant): the kernel also forms the adjoint gather
+// F* B* beta' that ||F*B*beta||^2 and ||F*B*beta + w.*alpha||^2 (:225,233-236) need -- beta' is in registers here, so the
+// edge passes of k_kkt never read beta again.  The gather is the cone kernel's (gather_tile.h: x-neighbours through
+// LDS, y-neighbours by lane shuffle, "t+1" entries of the previous cell carried in registers); for an edge inside the
+// tile the two sums are taken on the spot (one load of alpha), for an edge on the tile's right / upper border the raw
+// partial sums go to q2 / sx / sy exactly as in the cone pass and k_kkt_bnd completes them.  The q0 entries' share of
+// ||q||^2, ||alpha||^2, ... is left to the q-step in this mode.
+template <bool WEIGHTED, bool EDGES>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
                                                                const double *__restrict__ phi,
                                                                const double *__restrict__ alpha,
                                                                const double *__restrict__ weight,
                                                                double *__restrict__ partials) {
-    const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
-    const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
+    __shared__ double2 xch[EDGES ? 2 : 1][EDGES ? TILE_X : 1][EDGES ? 64 : 1];
+    const int lane = threadIdx.x, xl = threadIdx.y;
+    const i64 y = (i64)blockIdx.x * TILE_Y + lane;
+    const i64 x = (i64)blockIdx.y * TILE_X + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
+    const i64 yc = inb ? y : 0, xc = inb ? x : 0;      // clamped coordinates keep out-of-tile lanes harmless
     const i64 t0 = (i64)blockIdx.z * a.TC;
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
+    const bool lastChunk = (t1 == g.ncl);
+    // the gather needs the "t+1" entries of the cell in front of the chunk (recomputed, not stored) and one virtual
+    // step behind the last cell that emits the final edge layer
+    const i64 tstart = (EDGES && t0 > 0) ? t0 - 1 : t0;
+    const i64 tstop = (EDGES && lastChunk) ? t1 + 1 : t1;
+    const i64 nxblk = gridDim.y, nyblk = gridDim.x;
     double S[S_COUNT];
 #pragma unroll
     for (int i = 0; i < S_COUNT; ++i) S[i] = 0.0;
-    if (inb) {
-        EdgeQuad cur = load_edges(g, a.q, y, x, t0, c.sf);
-        EdgeQuad curo = load_edges(g, a.q_old, y, x, t0, c.sf);
-        for (i64 tl = t0; tl < t1; ++tl) {
-            const i64 i = y + g.ny * (x + g.nx * tl);
-            const EdgeQuad nxt = load_edges(g, a.q, y, x, tl + 1, c.sf);
-            const EdgeQuad nxto = load_edges(g, a.q_old, y, x, tl + 1, c.sf);
-            const double q0 = a.q[i];
-            double b[10], v[10], zo[10], p[10];
+    auto wgt = [&](i64 idx) { return WEIGHTED ? weight[idx] : 1.0; };
+    double p3 = 0.0, p4 = 0.0, p7 = 0.0, p8 = 0.0;     // beta' columns 4, 5, 8, 9 of the previous cell
+    int par = 0;
+    if (inb || EDGES) {
+        EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf);
+        EdgeQuad curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
+        for (i64 tl = tstart; tl < tstop; ++tl) {
+            const bool hasCell = tl < g.ncl;
+            const bool own = (tl >= t0) && inb;
+            double b[10];
+            if (hasCell) {
+                const i64 i = yc + g.ny * (xc + g.nx * tl);
+                const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
+                const EdgeQuad nxto = load_edges(g, a.q_old, yc, xc, tl + 1, c.sf);
+                const double q0 = a.q[i];
+                double v[10], zo[10], p[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
-            if (a.bpend) {
+                for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+                if (a.bpend) {
 #pragma unroll
-                for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
+                    for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
+                }
+                build_z2(v, q0, cur, nxt, c.s, c.dF);
+                build_z2(zo, a.q_old[i], curo, nxto, c.s, c.dF);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) zo[j] = zo[j] - b[j];
+                proj_row<10>(zo);
+                double zs = 0.0, bs = 0.0, rs = 0.0;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const double r = zo[j] - v[j];
+                    b[j] = b[j] + c.tau * r;
+                    p[j] = zo[j] - k.sigma * b[j];
+                    zs += zo[j] * zo[j];
+                    bs += b[j] * b[j];
+                    rs += r * r;
+                }
+                cur = nxt;
+                curo = nxto;
+                if (own) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
+                    proj_row<10>(p);
+                    double cs = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        const double d = zo[j] - p[j];
+                        cs += d * d;
+                    }
+                    S[S_Z2] += zs;
+                    S[S_BETA2] += bs;
+                    S[S_PRIM2] += rs;
+                    S[S_COMPLEM] += cs;
+                    const double w = wgt(i);
+                    const double av = alpha[i];
+                    const double rhoT = k.kappa * (w * av);
+                    double sq = 0.0;
+#pragma unroll
+                    for (int j = 1; j < 9; ++j) {
+                        const double e = k.dsE * v[j];
+                        sq += e * e;
+                    }
+                    double rhoFq = rhoT + k.dsD * q0 + sq / 4.0;
+                    rhoFq = (rhoFq < 0.0) ? 0.0 : rhoFq;
+                    const double dd = rhoT - rhoFq;
+                    S[S_DOTCOMP] += dd * dd;
+                    S[S_RHO2] += rhoT * rhoT;
+                    S[S_RHOFQ2] += rhoFq * rhoFq;
+                    // the q0 entry of q (same terms as the staggered edges in k_kkt)
+                    const double q2b = c.s * (b[9] - b[0]);
+                    const double wa = w * av;
+                    S[S_FBBETA2] += q2b * q2b;
+                    const double r2 = q2b + wa;
+                    S[S_DUAL2] += r2 * r2;
+                    if (!EDGES) {
+                        double tmp = (-c.at) * phi[i];
+                        tmp += c.at * phi[i + g.plane];
+                        const double wq = w * q0;
+                        S[S_Q2] += q0 * q0;
+                        S[S_ALPHA2] += av * av;
+                        S[S_APHI2] += tmp * tmp;
+                        const double r1 = tmp - wq;
+                        S[S_PRIM1] += r1 * r1;
+                        S[S_QALPHA] += wq * av;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) b[j] = 0.0;
             }
-            build_z2(v, q0, cur, nxt, c.s, c.dF);
-            build_z2(zo, a.q_old[i], curo, nxto, c.s, c.dF);
-#pragma unroll
-            for (int j = 0; j < 10; ++j) zo[j] = zo[j] - b[j];
-            proj_row<10>(zo);
-            double zs = 0.0, bs = 0.0, rs = 0.0;
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const double r = zo[j] - v[j];
-                b[j] = b[j] + c.tau * r;
-                a.beta_out[j * g.Nz + i] = b[j];
-                p[j] = zo[j] - k.sigma * b[j];
-                zs += zo[j] * zo[j];
-                bs += b[j] * b[j];
-                rs += r * r;
+            if (EDGES) {
+                // edge layer tl of F* B* beta' (gather_emit's arithmetic and order)
+                auto dual = [&](i64 e, double acc) {
+                    const double gb = c.sf * acc;
+                    S[S_FBBETA2] += gb * gb;
+                    const double r2 = gb + wgt(e) * alpha[e];
+                    S[S_DUAL2] += r2 * r2;
+                };
+                xch[par][xl][lane] = make_double2(b[1], p3);
+                __syncthreads();
+                if (own) {
+                    if (x < g.nx - 1) {
+                        const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+                        if (xl < TILE_X - 1) {
+                            const double2 r = xch[par][xl + 1][lane];
+                            double acc = r.x + b[2];
+                            acc += r.y;
+                            acc += p4;
+                            dual(e, acc);
+                        } else {
+                            a.q2[e] = b[2] + p4;             // partial; the right tile's part arrives in sx
+                        }
+                    }
+                    if (xl == 0 && x > 0) a.sx[(tl * nxblk + blockIdx.y) * g.ny + y] = b[1] + p3;
+                }
+                const double u5 = __shfl_down(b[5], 1, 64), u7 = __shfl_down(p7, 1, 64);
+                if (own) {
+                    if (y < g.ny - 1) {
+                        const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+                        if (lane < 63) {
+                            double acc = u5 + b[6];
+                            acc += u7;
+                            acc += p8;
+                            dual(e, acc);
+                        } else {
+                            a.q2[e] = b[6] + p8;             // partial; the upper tile's part arrives in sy
+                        }
+                    }
+                    if (lane == 0 && y > 0) a.sy[(tl * g.nx + x) * nyblk + blockIdx.x] = b[5] + p7;
+                }
+                p3 = b[3]; p4 = b[4]; p7 = b[7]; p8 = b[8];
+                par ^= 1;
             }
-            proj_row<10>(p);
-            double cs = 0.0;
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const double d = zo[j] - p[j];
-                cs += d * d;
-            }
-            S[S_Z2] += zs;
-            S[S_BETA2] += bs;
-            S[S_PRIM2] += rs;
-            S[S_COMPLEM] += cs;
-            const double w = WEIGHTED ? weight[i] : 1.0;
-            const double av = alpha[i];
-            const double rhoT = k.kappa * (w * av);
-            double sq = 0.0;
-#pragma unroll
-            for (int j = 1; j < 9; ++j) {
-                const double e = k.dsE * v[j];
-                sq += e * e;
-            }
-            double rhoFq = rhoT + k.dsD * q0 + sq / 4.0;
-            rhoFq = (rhoFq < 0.0) ? 0.0 : rhoFq;
-            const double dd = rhoT - rhoFq;
-            S[S_DOTCOMP] += dd * dd;
-            S[S_RHO2] += rhoT * rhoT;
-            S[S_RHOFQ2] += rhoFq * rhoFq;
-            // the q0 entry of q (same terms as the staggered edges in k_kkt)
-            double tmp = (-c.at) * phi[i];
-            tmp += c.at * phi[i + g.plane];
-            const double q2b = c.s * (b[9] - b[0]);
-            const double wq = w * q0, wa = w * av;
-            S[S_Q2] += q0 * q0;
-            S[S_ALPHA2] += av * av;
-            S[S_APHI2] += tmp * tmp;
-            const double r1 = tmp - wq;
-            S[S_PRIM1] += r1 * r1;
-            S[S_FBBETA2] += q2b * q2b;
-            const double r2 = q2b + wa;
-            S[S_DUAL2] += r2 * r2;
-            S[S_QALPHA] += wq * av;
-            cur = nxt;
-            curo = nxto;
         }
     }
     __shared__ double red[TILE_X][S_COUNT];
-    const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < S_COUNT; ++i) {
         double v = S[i];
@@ -294,8 +371,80 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
         double v = red[0][lane];
 #pragma unroll
         for (int wv = 1; wv < TILE_X; ++wv) v += red[wv][lane];
-        const i64 b = blockIdx.x + (i64)gridDim.x * (blockIdx.y + (i64)gridDim.y * blockIdx.z);
-        partials[b * S_COUNT + lane] = v;
+        const i64 bb = blockIdx.x + (i64)gridDim.x * (blockIdx.y + (i64)gridDim.y * blockIdx.z);
+        partials[bb * S_COUNT + lane] = v;
+    }
+}
+
+// The edges on tile borders (one slab).  DIR 0: bx edges (y, x+1/2, t) with x % TILE_X == TILE_X - 1 -- their right density
+// node and the x+1 cells of their adjoint gather live in the next tile; DIR 1: by edges (y+1/2, x, t) with y % 64 == 63.
+// Per edge: the momentum terms the q-step's KKT variant left out, and ||F*B*beta||^2, ||F*B*beta + w.*alpha||^2 from the raw
+// partial sums k_kkt_cells<., true> left in q2 / sx / sy.  alpha, q: the new iterates in memory.
+template <bool WEIGHTED, int DIR>
+__global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, FusedGeom fg, const double *__restrict__ q,
+                                                  const double *__restrict__ alpha, const double *__restrict__ weight,
+                                                  const double *__restrict__ q2, const double *__restrict__ sx,
+                                                  const double *__restrict__ sy, double *__restrict__ partials) {
+    auto wgt = [&](i64 idx) { return WEIGHTED ? weight[idx] : 1.0; };
+    auto rhoT_at = [&](i64 yy, i64 xx, i64 tl) -> double {
+        if (tl < 0 || tl >= g.ncl) return 0.0;
+        const i64 cidx = yy + g.ny * (xx + g.nx * tl);
+        return k.kappa * (wgt(cidx) * alpha[cidx]);
+    };
+    auto rho_node = [&](i64 yy, i64 xx, i64 tl) { return (rhoT_at(yy, xx, tl - 1) + rhoT_at(yy, xx, tl)) / 2.0; };
+    double sM = 0.0, sR = 0.0, sF = 0.0, sD = 0.0;
+    // DIR 0: threads along y, blockIdx.y = border column; DIR 1: threads along x, blockIdx.y = border row
+    const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 tl = blockIdx.z;
+    if (DIR == 0) {
+        const i64 y = u, x = (i64)blockIdx.y * TILE_X + (TILE_X - 1);
+        if (y < g.ny && x < g.nx - 1) {
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            const double rm = (rho_node(y, x, tl) + rho_node(y, x + 1, tl)) / 2.0;
+            const double rb = k.dsD * (rm * q[e]);
+            const double m = k.kappa * (wgt(e) * alpha[e]);
+            const double d = m - rb;
+            sM = d * d;
+            sR = rb * rb;
+            const double gb = c.sf * (q2[e] + sx[(tl * fg.nxblk + (x / TILE_X + 1)) * g.ny + y]);
+            sF = gb * gb;
+            const double r2 = gb + wgt(e) * alpha[e];
+            sD = r2 * r2;
+        }
+    } else {
+        const i64 x = u, y = (i64)blockIdx.y * 64 + 63;
+        if (x < g.nx && y < g.ny - 1) {
+            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            const double rm = (rho_node(y, x, tl) + rho_node(y + 1, x, tl)) / 2.0;
+            const double rb = k.dsD * (rm * q[e]);
+            const double m = k.kappa * (wgt(e) * alpha[e]);
+            const double d = m - rb;
+            sM = d * d;
+            sR = rb * rb;
+            const double gb = c.sf * (q2[e] + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
+            sF = gb * gb;
+            const double r2 = gb + wgt(e) * alpha[e];
+            sD = r2 * r2;
+        }
+    }
+    __shared__ double red[4][4];
+    double v4[4] = {sM, sR, sF, sD};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double v = v4[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < S_COUNT) {
+        const int s = threadIdx.x;
+        const int i = (s == S_MRHOB) ? 0 : (s == S_RHOB2) ? 1 : (s == S_FBBETA2) ? 2 : (s == S_DUAL2) ? 3 : -1;
+        double v = 0.0;
+        if (i >= 0) v = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        const i64 bb = blockIdx.x + (i64)gridDim.x * (blockIdx.y + (i64)gridDim.y * blockIdx.z);
+        partials[bb * S_COUNT + s] = v;
     }
 }
 
@@ -324,14 +473,21 @@ static void kkt_geometry(const Grid &g, dim3 &grid, i64 &chunk) {
     grid = dim3((unsigned)((g.ny + TILE_Y - 1) / TILE_Y), (unsigned)((g.nx + TILE_X - 1) / TILE_X), (unsigned)chunks);
 }
 
+static i64 bnd_blocks(const Grid &g, const FusedGeom &fg, int dir) {
+    if (dir == 0) return ((g.ny + 255) / 256) * fg.nxblk * g.ntl;
+    return ((g.nx + 255) / 256) * fg.nyblk * g.ntl;
+}
+
 static i64 kkt_region_blocks(const Grid &g) {
     dim3 grid;
     i64 chunk;
     kkt_geometry(g, grid, chunk);
     FusedGeom fg;
     fused_geometry(g, fg);
-    const i64 a = (i64)grid.x * grid.y * grid.z, b = fg.nyblk * fg.nxblk * fg.chunks;
-    return a > b ? a : b;
+    i64 m = (i64)grid.x * grid.y * grid.z;
+    const i64 cand[] = {fg.nyblk * fg.nxblk * fg.chunks, qstep_rhs_blocks(g, fg), bnd_blocks(g, fg, 0), bnd_blocks(g, fg, 1)};
+    for (i64 v : cand) m = v > m ? v : m;
+    return m;
 }
 
 // four regions (node, cell, bx, by launches) of per-workgroup partial sums; a region is as long as
@@ -362,21 +518,44 @@ int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double 
     return 0;
 }
 
-// fused path: pending multiplier step + cell sums in one pass (region 1); a.beta_out must differ from a.beta_in
+// fused path: pending multiplier step + cell sums in one pass (region 1); a.beta_out must differ from a.beta_in.
+// edges: the iteration's q-step ran in its KKT variant (region 0): this launch adds the F*B*beta' terms of all edges inside
+// the tiles and a second one (regions 2, 3) everything that is left on the tile borders; a.q2 / sx / sy are scratch then.
 int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, FusedArgs a,
                             const double *phi, const double *alpha, const double *weight, const KktWork &w,
-                            hipStream_t st) {
+                            hipStream_t st, bool edges, const double *q_new) {
     if (g.Nz <= 0) return 0;
     const i64 region = kkt_region_blocks(g);
     a.TC = fg.TC;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
     double *part = w.partials + 1 * region * S_COUNT;
-    if (weight)
-        hipLaunchKernelGGL(k_kkt_cells<true>, grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
-    else
-        hipLaunchKernelGGL(k_kkt_cells<false>, grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
+    const dim3 blk(TILE_Y, TILE_X);
+    if (!edges) {
+        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, false>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        else hipLaunchKernelGGL((k_kkt_cells<false, false>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        DS_HIP(hipGetLastError());
+        return 0;
+    }
+    if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    else hipLaunchKernelGGL((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
     DS_HIP(hipGetLastError());
+    for (int dir = 0; dir < 2; ++dir) {
+        const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;
+        if (len <= 0 || lines <= 0) continue;
+        dim3 gb((unsigned)((len + 255) / 256), (unsigned)lines, (unsigned)g.ntl);
+        double *pb = w.partials + (2 + dir) * region * S_COUNT;
+#define BND(W, D) hipLaunchKernelGGL((k_kkt_bnd<W, D>), gb, dim3(256), 0, st, g, c, k, fg, q_new, alpha, weight, a.q2, a.sx, a.sy, pb)
+        if (weight) { if (dir == 0) BND(true, 0); else BND(true, 1); }
+        else { if (dir == 0) BND(false, 0); else BND(false, 1); }
+#undef BND
+        DS_HIP(hipGetLastError());
+    }
     return 0;
+}
+
+double *kkt_qstep_partials(const Grid &g, const KktWork &w) {
+    (void)g;
+    return w.partials;       // region 0 (the node launch of the unfolded path uses it otherwise)
 }
 
 int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st) {

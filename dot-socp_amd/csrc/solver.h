@@ -164,6 +164,13 @@ struct Solver {
     bool zp_pend = false;            // the op that was pending on the kept beta^k (beta2) when it was read
     double zp_mul = 1.0, zp_div = 1.0;
     int flush_beta();
+    // same for alpha after a sigma update on the folded KKT path: the next q-step divides on load
+    bool apend = false;
+    double amul = 1.0, adiv = 1.0;
+    int flush_alpha();
+    int sigma_scale_folded(double factor);
+    bool kkt_fold = true;    // DOTSOCP_KKT_FOLD=0: KKT sums by the separate node / edge launches on every path
+    KktCoef kkt_coef() const;
     void set_pending(FusedArgs &a) const { a.bpend = bpend ? 1 : 0; a.bmul = bmul; a.bdiv = bdiv; }
     struct Pending { hipEvent_t a, b; int phase; };
     std::vector<Pending> pending;
@@ -194,11 +201,12 @@ struct Solver {
     int phase_z(bool on_z, int part = 0);
     int phase_z_tails();
     int ship_tails();        // time slabs: finalise + send the adjoint tails (-> right) and the phi head (-> left)
-    int phase_q(int part = 0);   // part 0: whole q-step; 1: the middle chunks on stream_z; 2: first + last chunk, then finish
+    // part 0: whole q-step; 1: the middle chunks on the second streams; 2: first + last chunk, then finish
+    int phase_q(int part = 0, bool kkt = false);
     int phase_mult();
     int materialise();
-    int kkt_sums(double *S);
-    int kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk);
+    int kkt_sums(double *S, bool folded = false);
+    int kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk, bool folded = false);
     int scale_state(double a_mul, double a_div, double q_div, bool with_c);
     void update_coef();
     double elapsed() const;

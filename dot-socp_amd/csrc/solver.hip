@@ -260,6 +260,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs, bool multi_dev) 
     overlap = nslabs > 1;                         // pays when there is communication to hide
     if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_QRHS")) qrhs = (atoi(e) != 0);
+    if (const char *e = getenv("DOTSOCP_KKT_FOLD")) kkt_fold = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_TSOLVE")) tri_tsolve = (strcmp(e, "dct") != 0);
     DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
     DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
@@ -758,6 +759,7 @@ int Solver::download(int field, double *host) {
         DS_CHECK(ensure_z());
         DS_CHECK(flush_beta());
     }
+    if (field == DOTSOCP_F_ALPHA) DS_CHECK(flush_alpha());
     DS_CHECK(copy_field(*this, field, host, false));
     // after finish(): var.alpha = sigma * alpha, var.beta = sigma * beta  (solver_socp_inPALM.m:335-336)
     if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) {
@@ -844,7 +846,29 @@ int Solver::flush_beta() {
     return 0;
 }
 
+int Solver::flush_alpha() {
+    if (!apend) return 0;
+    FOR_SLABS(s) DS_CHECK(launch_scale(s.alpha, s.g.NqAlloc, amul, adiv, s.st));
+    apend = false;
+    return 0;
+}
+
+// sigma update on the folded KKT path (one slab, fused dataflow): alpha, beta, c <- x / factor (solver_socp_inPALM.m:
+// 312-314) without a pass over alpha or q -- beta and alpha stay as they are and are divided on load by their next
+// reader (cone pass resp. q-step), and the right-hand side of the next phi-step is corrected with the r = A' alpha - c
+// the q-step stored: A'(w.*q - alpha / f) + c / f = (rhs + r) - r / f.  c is divided in that same small pass.
+int Solver::sigma_scale_folded(double factor) {
+    DS_CHECK(flush_beta());
+    DS_CHECK(flush_alpha());
+    bpend = true; bmul = 1.0; bdiv = factor;
+    apend = true; amul = 1.0; adiv = factor;
+    u0_fresh = false;
+    FOR_SLABS(s) DS_CHECK(launch_rhs_sigma_fix(s.w0, s.w1, s.c, s.g.Nphi, factor, s.st));
+    return 0;
+}
+
 int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
+    DS_CHECK(flush_alpha());
     u0_fresh = false;      // q0 / alpha0 change: the u0 tail held by the right neighbour is stale
     rhs_valid = false;     // ... and so is the right-hand side the last q-step left in w0
     if (fused && begun) {
@@ -987,6 +1011,7 @@ int Solver::phase_phi() {
     }
     prof_begin(PH_RHS);
     if (!rhs_valid) {
+        DS_CHECK(flush_alpha());
         FOR_SLABS(s) DS_CHECK(launch_rhs(s.g, lc, s.q, s.alpha, s.c, s.weight, s.u0_prev, s.w0, s.st));
     } else if (multi()) {
         // the q-step left rhs in w0; its first layer still lacks the left neighbour's last cell
@@ -1064,7 +1089,22 @@ int Solver::ship_tails() {
     return 0;
 }
 
-int Solver::phase_q(int part) {
+KktCoef Solver::kkt_coef() const {
+    KktCoef k;
+    k.sigma = sigma;
+    k.kappa = sigma * cScale * D;
+    k.dsD = dScale / D;
+    k.dsE = dScale / E;
+    return k;
+}
+
+// kkt: the iteration ends with a KKT check and the q-step runs in its KKT variant (one slab: part == 0)
+int Solver::phase_q(int part, bool kkt) {
+    if (!(fused && qrhs)) DS_CHECK(flush_alpha());
+    if (kkt) {
+        // all four regions of partial sums are cleared here; kkt_sums() then only adds the cell and border launches
+        FOR_SLABS(s) DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+    }
     if (part != 1) prof_begin(PH_QSTEP);
     FOR_SLABS(s) {
         hipStream_t st = (part == 1) ? s.st_z : s.st;
@@ -1078,8 +1118,16 @@ int Solver::phase_q(int part) {
                 i64 z0 = 0, zc = C, zs = 1;
                 if (part == 1) { z0 = 1; zc = C - 2; }             // the chunks in the middle
                 else if (part == 2) { zc = 2; zs = C - 1; }        // first and last chunk in one launch
+                QStepExtra ex{};
+                ex.apend = apend ? 1 : 0; ex.amul = amul; ex.adiv = adiv;
+                if (kkt) {
+                    const KktCoef k = kkt_coef();
+                    ex.partials = kkt_qstep_partials(s.g, s.kw);
+                    ex.resid = s.w1;                   // free between the Poisson solves
+                    ex.kappa = k.kappa; ex.dsD = k.dsD;
+                }
                 DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by, s.c,
-                                          s.q_old, s.alpha, s.alpha2, s.w0, st, z0, zc, zs));
+                                          s.q_old, s.alpha, s.alpha2, s.w0, st, z0, zc, zs, &ex));
                 if (part != 1) std::swap(s.alpha, s.alpha2);
             } else {
                 DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.weight, s.tail_bx, s.tail_by,
@@ -1089,6 +1137,7 @@ int Solver::phase_q(int part) {
         }
     }
     if (part == 1) return 0;
+    if (fused && qrhs) apend = false;        // the q-step wrote the scaled alpha into the ping-pong partner
     prof_end(PH_QSTEP);
     if (part == 2) {                                                    // the middle chunks (second streams)
         FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
@@ -1160,19 +1209,20 @@ int Solver::ensure_z() {
     return 0;
 }
 
-int Solver::kkt_sums(double *S) {
+// folded: this iteration's q-step ran in its KKT variant (phase_q(.., true)): region 0 of the partial sums holds its
+// share, the cell pass adds the F*B*beta terms of the edges, and no node / edge launch follows
+int Solver::kkt_sums(double *S, bool folded) {
     DS_CHECK(ensure_halo());
-    KktCoef k;
-    k.sigma = sigma;
-    k.kappa = sigma * cScale * D;
-    k.dsD = dScale / D;
-    k.dsE = dScale / E;
-    // the launches below write per-workgroup partial sums into four regions; grids of different
-    // shapes may use a region on different calls, so stale entries are cleared first
-    FOR_SLABS(s)
-        DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+    const KktCoef k = kkt_coef();
+    if (!folded) {
+        DS_CHECK(flush_alpha());
+        // the launches below write per-workgroup partial sums into four regions; grids of different
+        // shapes may use a region on different calls, so stale entries are cleared first
+        FOR_SLABS(s)
+            DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+    }
     // ---- cell part (region 1 of the partial sums) ----
-    int rest = 1 | 4 | 8;
+    int rest = folded ? 0 : (1 | 4 | 8);
     if (fused && deferred) {
         // pending multiplier step + cell sums in one pass; beta^k stays in beta2 so that z can be regenerated
         FOR_SLABS(s) {
@@ -1182,7 +1232,8 @@ int Solver::kkt_sums(double *S) {
             a.beta_in = s.beta;
             a.beta_out = s.beta2;
             set_pending(a);
-            DS_CHECK(launch_kkt_cells_update(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, s.st));
+            if (folded) { a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy; }      // scratch for the gather of beta on tile borders
+            DS_CHECK(launch_kkt_cells_update(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, s.st, folded, s.q));
             std::swap(s.beta, s.beta2);
         }
         // the kept beta^k (now in beta2) is still unscaled in memory: remember its pending op for MODE_Z
@@ -1192,6 +1243,7 @@ int Solver::kkt_sums(double *S) {
         z_valid = false;
         z_prev_ok = true;
     } else {
+        if (folded) { set_error("internal: folded KKT sums without a pending multiplier step"); return DOTSOCP_ESTATE; }
         DS_CHECK(ensure_z());
         DS_CHECK(flush_beta());
         rest |= 2;
@@ -1212,7 +1264,7 @@ int Solver::kkt_sums(double *S) {
     for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
     FOR_SLABS(s) {
         KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
-        DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, s.st));
+        if (rest) DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, s.st));
         DS_CHECK(launch_kkt_final(s.g, s.kw, s.st));
         if (remote()) break;
         DS_HIP(hipMemcpyAsync(s.h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s.st));
@@ -1317,10 +1369,10 @@ static void adjust_lagrangian_param(double &sigma, double xi, double &factor) { 
 }
 
 // solver_socp_inPALM.m:222-323
-int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
+int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk, bool folded) {
     double S[S_COUNT + 1];
     prof_begin(PH_KKT);
-    DS_CHECK(kkt_sums(S));
+    DS_CHECK(kkt_sums(S, folded));
     prof_end(PH_KKT);
     // one slab per process: the ranks must take the time-limit decision together, so it is taken
     // here from the maximum of their wall clocks (time-outs are detected at KKT checks only)
@@ -1374,7 +1426,8 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk) {
         double factor;
         adjust_lagrangian_param(sigma, resiPri / resiDual, factor);
         if (factor != 1.0) {
-            DS_CHECK(scale_state(1.0, factor, 1.0, true));
+            if (folded && rhs_valid) DS_CHECK(sigma_scale_folded(factor));
+            else DS_CHECK(scale_state(1.0, factor, 1.0, true));
             if (method == DOTSOCP_METHOD_ACCADMM) DS_CHECK(acc_on_sigma_factor(factor));
         }
     }
@@ -1391,6 +1444,11 @@ int Solver::step(bool *brk) {
     if (method == DOTSOCP_METHOD_PALM) return palm_step(brk);
     it += 1;
     DS_CHECK(rescale_block());
+    const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
+    // known before the q-step (the time limit is the one trigger that is not: such a check takes the unfolded path)
+    const bool kkt_due = opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit;
+    // one slab, fused dataflow: the q-step of a checking iteration accumulates its share of the KKT sums itself
+    const bool fold = kkt_due && kkt_fold && fused && qrhs && !multi();
     bool split = overlap && fused && halo_pending;
     for (auto &s : slabs) split = split && s.fg.chunks >= 2;
     if (split) {
@@ -1433,14 +1491,13 @@ int Solver::step(bool *brk) {
         DS_CHECK(phase_q(2));
     } else {
         DS_CHECK(phase_z_tails());
-        DS_CHECK(phase_q());
+        DS_CHECK(phase_q(0, fold));
     }
     DS_CHECK(phase_mult());
-    const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
     // with one slab per process a per-rank clock could split the ranks: see kkt_block()
     const bool timed_out = remote() ? false : (elapsed() > time_limit);
-    if (opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out)        // :221
-        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
+    if (kkt_due || timed_out)                                                             // :221
+        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk, fold));
     return 0;
 }
 
@@ -1469,6 +1526,7 @@ int Solver::finish(dotsocp_result *res) {
     DS_CHECK(use_dev(device));
     DS_CHECK(ensure_z());
     DS_CHECK(flush_beta());
+    DS_CHECK(flush_alpha());
     DS_CHECK(sync_all());
     DS_CHECK(prof_flush());
     if (canary_enabled()) {        // DOTSOCP_CANARY=1: no kernel of this solve wrote outside its buffers

@@ -278,11 +278,19 @@ int launch_qstep_fused(const Grid &g, const LoopCoef &c, const FusedGeom &fg, co
 //   after the u0 exchange.
 // ---------------------------------------------------------------------------------------
 // MULT 0: alpha + tau (A phi - w q) (inPALM); 1: (alpha + A phi) - w q (acc-ADMM); 2: alpha stays (PALM's first q-step)
+// A scaling of alpha that is still pending in memory (sigma update, solver_socp_inPALM.m:312: alpha = alpha / factor) is
+// applied on load with k_scale's arithmetic; the q-step writes the scaled values into the ping-pong partner.
+struct APend {
+    int on;
+    double mul, div;
+};
+
 template <bool WEIGHTED, int MULT = 0>
 __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, i64 k,
                                           const double *__restrict__ weight, const double *__restrict__ alpha_in,
-                                          double &qn, double &an, double &u) {
-    const double a = alpha_in[k];
+                                          double &qn, double &an, double &u, const APend &ap = APend{0, 1.0, 1.0}) {
+    double a = alpha_in[k];
+    if (ap.on) a = a * ap.mul / ap.div;
     if (WEIGHTED) {
         const double w = weight[k];
         const double di = 1.0 / (diag_c + w * w);
@@ -323,14 +331,47 @@ struct QRhsArgs {
     double *q_state;
     const double *q_anchor, *alpha_anchor;
     double c1, c2, om_rho, rho;
+    APend ap;          // pending scaling of alpha_in (VAR 0)
+    // KKT variant (VAR 0, single slab): per-workgroup partial sums, r = A' alpha^+ - c per node, DOT complementarity scalars
+    double *partials, *resid;
+    double kappa, dsD;
 };
 
 // VAR 0: inPALM / ALG2; 1: acc-ADMM multiplier arithmetic, raw outputs; 2: acc-ADMM with the Halpern step of q and
 // alpha folded in (solver_socp_accADMM.m:373-379); 3: PALM's first q-step (q only, solver_socp_PALM.m:196-200).
 // The rhs is formed from the raw u = w.*q^+ - alpha^+ in all cases (VAR 3: alpha^+ = alpha)
-template <bool WEIGHTED, int VAR>
+//
+// KKT = true (VAR 0, one slab): the iteration ends with a KKT check (solver_socp_inPALM.m:220-267).  Everything of that
+// block that depends on phi^{k+1}, q^{k+1}, alpha^{k+1}, A phi and c only is accumulated here, where those values are in
+// registers anyway: ||q||^2, ||alpha||^2, ||A phi||^2, ||A phi - w q||^2, <w q, alpha>, <c, phi>, ||phi||^2,
+// ||A' alpha - c||^2 (a second accumulation next to the rhs, alpha of the x-1 / y-1 / t-1 entries travelling beside u) and
+// the momentum terms of compute_kkt_dot_complement.m:10-18 for all edges whose two density nodes lie in this tile (the
+// edges on the tile's right / upper border are left to k_kkt_bnd).  r = A' alpha - c is also stored per node: after a
+// sigma update the right-hand side of the next phi-step is rhs + r - r / factor (launch_rhs_sigma_fix) instead of a new pass.
+enum { Q_Q2 = 0, Q_ALPHA2, Q_APHI2, Q_PRIM1, Q_QALPHA, Q_CPHI, Q_PHI2, Q_DUAL1, Q_MRHOB, Q_M2, Q_RHOB2, Q_COUNT };
+
+template <bool WEIGHTED, int VAR, bool KKT = false>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
     __shared__ double xch[2][TILE_X][TILE_Y];
+    __shared__ double xcha[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // alpha^+ of the bx edge
+    __shared__ double xchr[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // density at the node
+    double S[Q_COUNT];     // KKT only (dead code otherwise)
+    if (KKT) {
+#pragma unroll
+        for (int i = 0; i < Q_COUNT; ++i) S[i] = 0.0;
+    }
+    auto wgt = [&](i64 k) { return WEIGHTED ? a.weight[k] : 1.0; };
+    // sums every staggered entry contributes to (edge_sums of k_kkt)
+    auto entry = [&](double tmp, double qn, double an, double w) {
+        const double wq = w * qn;
+        S[Q_Q2] += qn * qn;
+        S[Q_ALPHA2] += an * an;
+        S[Q_APHI2] += tmp * tmp;
+        const double r1 = tmp - wq;
+        S[Q_PRIM1] += r1 * r1;
+        S[Q_QALPHA] += wq * an;
+    };
+    double a0prev = 0.0, rhoTprev = 0.0;
     const int lane = threadIdx.x, xl = threadIdx.y;
     const i64 y = (i64)blockIdx.x * TILE_Y + lane;
     const i64 x = (i64)blockIdx.y * TILE_X + xl;
@@ -373,7 +414,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
             double tmp = (-c.at) * a.phi[k];
             tmp += c.at * p0;
             double qn, an;
-            q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev);
+            q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev, a.ap);
+            if (KKT) {
+                a0prev = an;
+                rhoTprev = a.kappa * (wgt(k) * an);
+            }
         }
     }
     int par = 0;
@@ -383,45 +428,80 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
         const double dc = tbnd ? c.c2 : c.c1;
         const double di = tbnd ? c.dinv2 : c.dinv1;
         double pT = 0.0, u0 = 0.0, ubx = 0.0, uby = 0.0;
+        double a0 = 0.0, abx = 0.0, aby = 0.0;                 // KKT: alpha^+ of the own entries
+        double qbx = 0.0, mbx = 0.0, qby = 0.0, mby = 0.0;     // KKT: q^+ and momentum kappa (w alpha^+) of the own edges
+        double rhoT = 0.0;                                     // KKT: density of the cell that starts at this node
         if (inb) {
             double qn, an;
             if (tl < g.ncl) {
                 pT = a.phi[node + g.plane];
                 double tmp = (-c.at) * p0;
                 tmp += c.at * pT;
-                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0);
+                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0, a.ap);
                 put(node, qn, an, ain);
                 if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
+                if (KKT) {
+                    const double w = wgt(node);
+                    entry(tmp, qn, an, w);
+                    a0 = an;
+                    rhoT = a.kappa * (w * an);
+                }
             }
             if (x < g.nx - 1) {
                 const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
                 double tmp = (-c.ax) * p0;
                 tmp += c.ax * a.phi[node + g.ny];
-                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx);
+                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx, a.ap);
                 put(e, qn, an, ain);
+                if (KKT) {
+                    const double w = wgt(e);
+                    entry(tmp, qn, an, w);
+                    abx = an;
+                    qbx = qn;
+                    mbx = a.kappa * (w * an);
+                    S[Q_M2] += mbx * mbx;
+                }
             }
             if (y < g.ny - 1) {
                 const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
                 double tmp = (-c.ay) * p0;
                 tmp += c.ay * a.phi[node + 1];
-                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby);
+                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby, a.ap);
                 put(e, qn, an, ain);
+                if (KKT) {
+                    const double w = wgt(e);
+                    entry(tmp, qn, an, w);
+                    aby = an;
+                    qby = qn;
+                    mby = a.kappa * (w * an);
+                    S[Q_M2] += mby * mby;
+                }
             }
         }
+        // density at the node: mean of the two cells that meet there in time, zero outside (movmean's padding)
+        const double rhoN = (rhoTprev + rhoT) / 2.0;
         xch[par][xl][lane] = ubx;
+        if (KKT) {
+            xcha[par][xl][lane] = abx;
+            xchr[par][xl][lane] = rhoN;
+        }
         __syncthreads();
         double uby_m = __shfl_up(uby, 1, 64);
+        double aby_m = KKT ? __shfl_up(aby, 1, 64) : 0.0;
+        const double rhoU = KKT ? __shfl_down(rhoN, 1, 64) : 0.0;
         if (inb) {
-            double ubx_m = 0.0;
+            double ubx_m = 0.0, abx_m = 0.0;
             if (x >= 1) {
                 if (xl > 0) {
                     ubx_m = xch[par][xl - 1][lane];
+                    if (KKT) abx_m = xcha[par][xl - 1][lane];
                 } else {            // edge owned by the tile to the left
                     const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * (x - 1);
                     double tmp = (-c.ax) * a.phi[node - g.ny];
                     tmp += c.ax * p0;
                     double qn, an;
-                    q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m);
+                    q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m, a.ap);
+                    abx_m = an;
                 }
             }
             if (y >= 1 && lane == 0) {      // edge owned by the tile below
@@ -429,7 +509,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 double tmp = (-c.ay) * a.phi[node - 1];
                 tmp += c.ay * p0;
                 double qn, an;
-                q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m);
+                q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m, a.ap);
+                aby_m = an;
             }
             double r = 0.0;
             if (tl >= 1) r += c.at * u0prev;
@@ -438,11 +519,70 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
             if (x <= g.nx - 2) r += (-c.ax) * ubx;
             if (y >= 1) r += c.ay * uby_m;
             if (y <= g.ny - 2) r += (-c.ay) * uby;
-            a.rhs[node] = r + a.cvec[node];
+            const double cv = a.cvec[node];
+            a.rhs[node] = r + cv;
+            if (KKT) {
+                double ra = 0.0;                       // A' alpha^+ in the order of k_kkt's node part
+                if (tl >= 1) ra += c.at * a0prev;
+                if (tl < g.ncl) ra += (-c.at) * a0;
+                if (x >= 1) ra += c.ax * abx_m;
+                if (x <= g.nx - 2) ra += (-c.ax) * abx;
+                if (y >= 1) ra += c.ay * aby_m;
+                if (y <= g.ny - 2) ra += (-c.ay) * aby;
+                ra = ra - cv;
+                a.resid[node] = ra;
+                S[Q_DUAL1] += ra * ra;
+                S[Q_CPHI] += cv * p0;
+                S[Q_PHI2] += p0 * p0;
+                // compute_kkt_dot_complement.m:10-18: momentum against mean density times b, edges inside the tile
+                if (x < g.nx - 1 && xl < TILE_X - 1) {
+                    const double rm = (rhoN + xchr[par][xl + 1][lane]) / 2.0;
+                    const double rb = a.dsD * (rm * qbx);
+                    const double d = mbx - rb;
+                    S[Q_MRHOB] += d * d;
+                    S[Q_RHOB2] += rb * rb;
+                }
+                if (y < g.ny - 1 && lane < TILE_Y - 1) {
+                    const double rm = (rhoN + rhoU) / 2.0;
+                    const double rb = a.dsD * (rm * qby);
+                    const double d = mby - rb;
+                    S[Q_MRHOB] += d * d;
+                    S[Q_RHOB2] += rb * rb;
+                }
+            }
         }
         u0prev = u0;
+        if (KKT) {
+            a0prev = a0;
+            rhoTprev = rhoT;
+        }
         p0 = pT;
         par ^= 1;
+    }
+    if (KKT) {
+        // workgroup reduction as in k_kkt: wavefront shuffles, LDS across the four wavefronts, one partial row per workgroup
+        __shared__ double red[TILE_X][Q_COUNT];
+        static const int slot[Q_COUNT] = {S_Q2, S_ALPHA2, S_APHI2, S_PRIM1, S_QALPHA, S_CPHI, S_PHI2, S_DUAL1, S_MRHOB, S_M2, S_RHOB2};
+#pragma unroll
+        for (int i = 0; i < Q_COUNT; ++i) {
+            double v = S[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[xl][i] = v;
+        }
+        __syncthreads();
+        if (xl == 0 && lane < S_COUNT) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < Q_COUNT; ++i)
+                if (slot[i] == lane) {
+                    v = red[0][i];
+#pragma unroll
+                    for (int wv = 1; wv < TILE_X; ++wv) v += red[wv][i];
+                }
+            const i64 b = blockIdx.x + (i64)gridDim.x * (blockIdx.y + (i64)gridDim.y * blockIdx.z);
+            a.partials[b * S_COUNT + lane] = v;
+        }
     }
 }
 
@@ -452,11 +592,41 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
                      const double *tail_by, const double *cvec, double *q_out, const double *alpha_in, double *alpha_out,
-                     double *rhs, hipStream_t st, i64 z0, i64 zcount, i64 zstride) {
+                     double *rhs, hipStream_t st, i64 z0, i64 zcount, i64 zstride, const QStepExtra *ex) {
     QRhsArgs a{};
     a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.weight = weight; a.tail_bx = tail_bx; a.tail_by = tail_by;
     a.cvec = cvec; a.alpha_in = alpha_in; a.q_out = q_out; a.alpha_out = alpha_out; a.rhs = rhs;
+    a.ap = APend{0, 1.0, 1.0};
+    if (ex) {
+        a.ap = APend{ex->apend, ex->amul, ex->adiv};
+        a.partials = ex->partials;
+        a.resid = ex->resid;
+        a.kappa = ex->kappa;
+        a.dsD = ex->dsD;
+    }
     return launch_qstep_rhs_var(0, g, c, fg, a, st, z0, zcount, zstride);
+}
+
+// blocks of the q-step launch: one row of partial sums each in the KKT variant
+i64 qstep_rhs_blocks(const Grid &g, const FusedGeom &fg) { return fg.nyblk * fg.nxblk * qstep_rhs_chunks(g, fg); }
+
+// After a sigma update (alpha, c <- / factor, solver_socp_inPALM.m:312-314) the right-hand side A'(w.*q - alpha) + c the
+// q-step left behind becomes  A'(w.*q) - (A' alpha - c) / factor = (rhs + r) - r / factor  with the r = A' alpha - c the
+// KKT variant of the q-step stored; c is divided on the way (alpha stays pending: APend).
+__global__ void __launch_bounds__(256) k_rhs_sigma_fix(double *__restrict__ rhs, const double *__restrict__ r,
+                                                        double *__restrict__ cvec, i64 n, double factor) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const double rv = r[i];
+        rhs[i] = (rhs[i] + rv) - rv / factor;
+        cvec[i] = cvec[i] / factor;
+    }
+}
+
+int launch_rhs_sigma_fix(double *rhs, const double *r, double *cvec, i64 n, double factor, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_rhs_sigma_fix, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, rhs, r, cvec, n, factor);
+    DS_HIP(hipGetLastError());
+    return 0;
 }
 
 // var 1 / 2: the acc-ADMM flavours (see k_qstep_rhs); `acc` carries the Halpern weights and the extra arrays of var 2
@@ -506,7 +676,10 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(TILE_Y, TILE_X);
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
-    if (a.weight) {
+    if (var == 0 && a.partials) {          // iteration with a KKT check
+        if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
+        else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
+    } else if (a.weight) {
         if (var == 0) QRHS_LAUNCH(true, 0); else if (var == 1) QRHS_LAUNCH(true, 1); else QRHS_LAUNCH(true, 2);
     } else {
         if (var == 0) QRHS_LAUNCH(false, 0); else if (var == 1) QRHS_LAUNCH(false, 1);

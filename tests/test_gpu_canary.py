@@ -85,8 +85,17 @@ def test_an_overrun_is_caught(monkeypatch):
     monkeypatch.setenv("DOTSOCP_CANARY", "1")
     monkeypatch.setenv("DOTSOCP_CANARY_SELFTEST", "1")
     rho0, rho1 = get_example_2d("example1", 20, 12)
-    with pytest.raises(capi.DotsocpError) as ei:
-        _solve(rho0, rho1, 6, 3)
-    assert "canary" in str(ei.value) and "behind the payload at word 0" in str(ei.value)
+    var, model = D.initialize(rho0, rho1, 6)
+    o = OD.default_opts(dict(tol=0.0, maxit=3), "inPALM", False)
+    D.InitialScaling(var, model, True, None, dim=2)
+    ctx = D.InPALMContext(var, o, model)
+    try:
+        ctx.run(-1)
+        with pytest.raises(capi.DotsocpError) as ei:
+            ctx.finish(download=False)
+        assert "canary" in str(ei.value) and "behind the payload at word 0" in str(ei.value)
+        assert capi.lib().dotsocp_canary_check() == 1          # the standalone check sees the same damage
+    finally:
+        ctx.close()
     monkeypatch.delenv("DOTSOCP_CANARY_SELFTEST")
-    assert capi.lib().dotsocp_canary_check() == 0          # the damaged context is gone
+    assert capi.lib().dotsocp_canary_check() == 0              # the damaged context is gone

@@ -1,0 +1,84 @@
+"""The folded KKT path (one slab, fused dataflow): on an iteration that ends with a KKT check the q-step kernel
+accumulates every sum that needs only phi, q^+, alpha^+, A phi and c (k_qstep_rhs<., 0, true>), the cell pass adds the
+F*B*beta terms of the edges inside its tiles (k_kkt_cells<., true>), a small launch finishes the edges on tile borders
+(k_kkt_bnd), and a sigma update corrects the stored right-hand side instead of recomputing it (k_rhs_sigma_fix, alpha
+divided on load by the next q-step).  Checked against the unfolded path of the same library (DOTSOCP_KKT_FOLD=0:
+separate node / edge launches, eager scalings, new rhs pass) -- both are also compared with the oracle by the
+trajectory tests -- on shapes with partial tiles, several chunks per tile, weights, 1-D, step-by-step checks."""
+import numpy as np
+import pytest
+
+import dotsocp_amd as D
+from oracle import driver as OD
+from oracle.examples import (ensure_barrier_validity, gene_barrier_of_circle_pillar, get_example_1d,
+                             get_example_2d, get_weight_by_barrier)
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("phi", "q", "z", "alpha", "beta")
+
+
+def _run(rho0, rho1, nt, opts, weight=None):
+    dim = 2 if np.ndim(rho0) == 2 else 1
+    var, model = D.initialize(rho0, rho1, nt)
+    if weight is not None:
+        model.weight = np.asarray(weight, dtype=np.float64)
+    o = OD.default_opts(opts, "inPALM", weight is not None)
+    D.InitialScaling(var, model, o["scaling"], None, dim=dim, weighted=weight is not None)
+    solve = D.solver_wsocp_inPALM if weight is not None else D.solver_socp_inPALM
+    hist, sigma = solve(var, o, model)
+    return var, hist, sigma
+
+
+def _both(monkeypatch, rho0, rho1, nt, opts, weight=None, tol=1e-12):
+    monkeypatch.setenv("DOTSOCP_KKT_FOLD", "0")
+    ref, h0, s0 = _run(rho0, rho1, nt, opts, weight)
+    monkeypatch.setenv("DOTSOCP_KKT_FOLD", "1")
+    got, h1, s1 = _run(rho0, rho1, nt, opts, weight)
+    np.testing.assert_array_equal(h1["iter"], h0["iter"])
+    assert abs(s1 - s0) <= 1e-13 * abs(s0)
+    # columns: every residual but the exact-cancellation one (5) to 1e-9 relative; that one is rounding noise
+    np.testing.assert_allclose(h1["kkt"], h0["kkt"], rtol=1e-9, atol=1e-10 if weight is None else 1e-9)
+    np.testing.assert_allclose(h1["pdGap"], h0["pdGap"], rtol=1e-9, atol=1e-15)
+    for f in FIELDS:
+        a, b = getattr(got, f), getattr(ref, f)
+        err = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        assert err <= tol, (f, err)
+
+
+@pytest.mark.parametrize("ny,nx,nt,K", [(32, 32, 16, 40), (100, 70, 20, 30), (65, 129, 33, 25), (63, 5, 7, 20), (5, 3, 4, 12),
+                                         (2, 2, 2, 6), (129, 3, 5, 15), (256, 256, 64, 30)])
+def test_folded_equals_unfolded(ny, nx, nt, K, monkeypatch):
+    if ny * nx <= 6:
+        rho0 = np.ones((ny, nx))
+        rho1 = np.ones((ny, nx))
+        rho1.flat[0] = 1.5
+        rho1 /= rho1.mean()
+    else:
+        rho0, rho1 = get_example_2d("example1", ny, nx)
+    _both(monkeypatch, rho0, rho1, nt, dict(tol=0.0, maxit=K))
+
+
+def test_folded_step_by_step_alg2_and_no_scaling(monkeypatch):
+    rho0, rho1 = get_example_2d("example1", 24, 40)
+    _both(monkeypatch, rho0, rho1, 12, dict(tol=0.0, maxit=15, ifCheckStepByStep=True))
+    _both(monkeypatch, rho0, rho1, 12, dict(tol=0.0, maxit=20, scaling=False, sigma=0.1))
+
+
+def test_folded_weighted_and_1d(monkeypatch):
+    rho0, rho1 = get_example_2d("example1", 33, 47)
+    barrier = gene_barrier_of_circle_pillar()
+    weight = get_weight_by_barrier(47, 33, 13, barrier)
+    rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    _both(monkeypatch, rho0, rho1, 13, dict(tol=0.0, maxit=25), weight=weight, tol=1e-9)
+    r0, r1 = get_example_1d("gaussian", 129)
+    _both(monkeypatch, r0, r1, 33, dict(tol=0.0, maxit=60))
+
+
+def test_folded_free_running_stops_like_unfolded(monkeypatch):
+    rho0, rho1 = get_example_2d("example1", 32, 32)
+    monkeypatch.setenv("DOTSOCP_KKT_FOLD", "0")
+    ref, h0, s0 = _run(rho0, rho1, 16, dict(tol=1e-4))
+    monkeypatch.setenv("DOTSOCP_KKT_FOLD", "1")
+    got, h1, s1 = _run(rho0, rho1, 16, dict(tol=1e-4))
+    assert h1["iter"][-1] == h0["iter"][-1] and h1["len"] == h0["len"]
+    np.testing.assert_allclose(h1["kkt"], h0["kkt"], rtol=1e-6, atol=1e-10)
