@@ -58,13 +58,23 @@ struct EdgeQuad {
 
 __device__ __forceinline__ EdgeQuad load_edges(const Grid &g, const double *__restrict__ q, i64 y, i64 x,
                                                i64 tt, double sf) {
+    // All four loads are issued unconditionally from clamped (always valid) addresses and the out-of-domain ones are
+    // replaced by zeros afterwards: straight-line code, the loads leave together and are waited for once.  (A load
+    // under its own `if` is followed by its own wait -- four serialised memory latencies per step of a t-marching
+    // kernel.)  Grids without bx (nx = 1: the 1-D problems) or by entries read the q0 block instead.
+    const double *bx = (g.nx >= 2) ? q + g.offBx + g.bxLayer * tt : q;
+    const double *by = (g.ny >= 2) ? q + g.offBy + g.byLayer * tt : q;
+    const i64 nxe = (g.nx >= 2) ? g.nx - 2 : 0, nye = (g.ny >= 2) ? g.ny - 2 : 0;   // last edge index
+    const i64 rowy = (g.ny >= 2) ? g.ny - 1 : 0;                                     // by row length
+    const i64 xm = (x >= 1) ? x - 1 : 0, xp = (x <= nxe) ? x : nxe;
+    const i64 ym = (y >= 1) ? y - 1 : 0, yp = (y <= nye) ? y : nye;
+    const double vxm = bx[y + g.ny * xm], vxp = bx[y + g.ny * xp];
+    const double vym = by[ym + rowy * x], vyp = by[yp + rowy * x];
     EdgeQuad e;
-    const double *bx = q + g.offBx + g.bxLayer * tt;
-    const double *by = q + g.offBy + g.byLayer * tt;
-    e.xm = (x >= 1) ? sf * bx[y + g.ny * (x - 1)] : 0.0;
-    e.xp = (x <= g.nx - 2) ? sf * bx[y + g.ny * x] : 0.0;
-    e.ym = (y >= 1) ? sf * by[(y - 1) + (g.ny - 1) * x] : 0.0;
-    e.yp = (y <= g.ny - 2) ? sf * by[y + (g.ny - 1) * x] : 0.0;
+    e.xm = (x >= 1) ? sf * vxm : 0.0;
+    e.xp = (x <= g.nx - 2) ? sf * vxp : 0.0;
+    e.ym = (y >= 1) ? sf * vym : 0.0;
+    e.yp = (y <= g.ny - 2) ? sf * vyp : 0.0;
     return e;
 }
 

@@ -65,6 +65,10 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             if (a.bpend) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
+                if (a.bpend > 1) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul2 / a.bdiv2;
+                }
             }
             build_z2(v, a.q[i], cur, nxt, c.s, c.dF);
             if (MODE != 0) {

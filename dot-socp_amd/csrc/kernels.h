@@ -63,8 +63,9 @@ struct FusedArgs {
     i64 TC;
     // pending scaling of beta_in (sigma update / rescale block, solver_socp_inPALM.m:176,313), applied on
     // load exactly like k_scale would have: b = b * bmul / bdiv
-    int bpend;
+    int bpend;              // number of pending operations (0, 1 or 2: a sigma update followed by a rescale)
     double bmul, bdiv;
+    double bmul2, bdiv2;    // second pending operation, applied after the first
     int xcd;                // permute the tile order so that y-neighbouring tiles share an XCD (device_utils.h)
     int z0;                 // first chunk of this launch (launch_cone_fused can launch a range of chunks)
 };
@@ -191,10 +192,11 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
                      const double *back, double *x, double *qinv, hipStream_t st);
 
 // ---------------- kkt.hip ----------------
+#define KKT_SLICES 64
 struct KktWork {
     double *partials;   // [maxBlocks][S_COUNT]
     i64 maxBlocks;
-    double *sums;       // [S_COUNT] device
+    double *sums;       // [S_COUNT] device, followed by [KKT_SLICES][S_COUNT] intermediate sums (launch_kkt_final)
 };
 // Halo layers from the LEFT neighbour slab's last cell (all nullptr on the first slab):
 // alpha0, w.*alpha0, and the partial adjoint sums of beta (columns 4,5 / 8,9).

@@ -9,6 +9,8 @@
 #include "gather_tile.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace dotsocp {
 
 struct WBeta {
@@ -200,8 +202,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
 // tile the two sums are taken on the spot (one load of alpha), for an edge on the tile's right / upper border the raw
 // partial sums go to q2 / sx / sy exactly as in the cone pass and k_kkt_bnd completes them.  The q0 entries' share of
 // ||q||^2, ||alpha||^2, ... is left to the q-step in this mode.
-template <bool WEIGHTED, bool EDGES>
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
+template <bool WEIGHTED, bool EDGES, int OCC = 1>
+__global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
                                                                const double *__restrict__ phi,
                                                                const double *__restrict__ alpha,
                                                                const double *__restrict__ weight,
@@ -238,12 +240,16 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
                 const EdgeQuad nxto = load_edges(g, a.q_old, yc, xc, tl + 1, c.sf);
                 const double q0 = a.q[i];
-                double v[10], zo[10], p[10];
+                double v[10], zo[10];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
                 if (a.bpend) {
 #pragma unroll
                     for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
+                    if (a.bpend > 1) {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul2 / a.bdiv2;
+                    }
                 }
                 build_z2(v, q0, cur, nxt, c.s, c.dF);
                 build_z2(zo, a.q_old[i], curo, nxto, c.s, c.dF);
@@ -255,7 +261,6 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 for (int j = 0; j < 10; ++j) {
                     const double r = zo[j] - v[j];
                     b[j] = b[j] + c.tau * r;
-                    p[j] = zo[j] - k.sigma * b[j];
                     zs += zo[j] * zo[j];
                     bs += b[j] * b[j];
                     rs += r * r;
@@ -265,11 +270,21 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 if (own) {
 #pragma unroll
                     for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
-                    proj_row<10>(p);
-                    double cs = 0.0;
+                    // ||z - Pi_Q(z - sigma beta')||^2 (:240-241) with proj_row's arithmetic, the projected row never
+                    // stored: x = z - sigma beta' is cheap to form twice, ten registers are not
+                    auto xj = [&](int j) { return zo[j] - k.sigma * b[j]; };
+                    double nn = xj(1) * xj(1);
 #pragma unroll
-                    for (int j = 0; j < 10; ++j) {
-                        const double d = zo[j] - p[j];
+                    for (int j = 2; j < 10; ++j) nn += xj(j) * xj(j);
+                    const double n = sqrt(nn), x0 = xj(0);
+                    double cf = (x0 / n + 1.0) * 0.5;
+                    cf = (cf > 1.0) ? 1.0 : cf;
+                    cf = (cf < 0.0) ? 0.0 : cf;
+                    const double p0 = (cf >= 1.0) ? x0 : cf * n;
+                    double cs = (zo[0] - p0) * (zo[0] - p0);
+#pragma unroll
+                    for (int j = 1; j < 10; ++j) {
+                        const double d = zo[j] - cf * xj(j);
                         cs += d * d;
                     }
                     S[S_Z2] += zs;
@@ -448,11 +463,15 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
     }
 }
 
+// Fixed-order reduction of the per-workgroup partial sums, in two levels (the q-step's KKT variant alone leaves tens of
+// thousands of rows): block (s, j) adds sum s over the j-th slice of rows, a second launch adds the KKT_SLICES slices.
 __global__ void __launch_bounds__(256) k_kkt_final(const double *__restrict__ partials, i64 nblocks,
                                                     double *__restrict__ sums) {
     const int s = blockIdx.x;
+    const i64 per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const i64 b0 = (i64)blockIdx.y * per, b1 = (b0 + per < nblocks) ? b0 + per : nblocks;
     double v = 0.0;
-    for (i64 b = threadIdx.x; b < nblocks; b += 256) v += partials[b * S_COUNT + s];
+    for (i64 b = b0 + threadIdx.x; b < b1; b += 256) v += partials[b * S_COUNT + s];
     __shared__ double red[256];
     red[threadIdx.x] = v;
     __syncthreads();
@@ -460,7 +479,15 @@ __global__ void __launch_bounds__(256) k_kkt_final(const double *__restrict__ pa
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) sums[s] = red[0];
+    if (threadIdx.x == 0) sums[(i64)blockIdx.y * S_COUNT + s] = red[0];
+}
+
+__global__ void __launch_bounds__(64) k_kkt_final2(const double *__restrict__ slices, int nslices, double *__restrict__ sums) {
+    const int s = threadIdx.x;
+    if (s >= S_COUNT) return;
+    double v = 0.0;
+    for (int j = 0; j < nslices; ++j) v += slices[(i64)j * S_COUNT + s];
+    sums[s] = v;
 }
 
 static void kkt_geometry(const Grid &g, dim3 &grid, i64 &chunk) {
@@ -536,8 +563,14 @@ int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, 
         DS_HIP(hipGetLastError());
         return 0;
     }
-    if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-    else hipLaunchKernelGGL((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    static const int occ = getenv("DOTSOCP_KKT_OCC") ? atoi(getenv("DOTSOCP_KKT_OCC")) : 0;
+    if (occ) {
+        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true, 3>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        else hipLaunchKernelGGL((k_kkt_cells<false, true, 3>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    } else {
+        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        else hipLaunchKernelGGL((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    }
     DS_HIP(hipGetLastError());
     for (int dir = 0; dir < 2; ++dir) {
         const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;
@@ -559,7 +592,10 @@ double *kkt_qstep_partials(const Grid &g, const KktWork &w) {
 }
 
 int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st) {
-    hipLaunchKernelGGL(k_kkt_final, dim3(S_COUNT), dim3(256), 0, st, w.partials, 4 * kkt_region_blocks(g), w.sums);
+    // w.sums: [S_COUNT] result followed by [KKT_SLICES][S_COUNT] intermediate sums
+    hipLaunchKernelGGL(k_kkt_final, dim3(S_COUNT, KKT_SLICES), dim3(256), 0, st, w.partials, 4 * kkt_region_blocks(g),
+                       w.sums + S_COUNT);
+    hipLaunchKernelGGL(k_kkt_final2, dim3(1), dim3(64), 0, st, w.sums + S_COUNT, KKT_SLICES, w.sums);
     DS_HIP(hipGetLastError());
     return 0;
 }

@@ -159,19 +159,28 @@ struct Solver {
     bool z_prev_ok = false;  // s.beta2 / s.q_old still hold (beta^k, q^k): z can be regenerated (MODE_Z)
     int ensure_z();
     // fused path: a scaling of beta that the next pass over beta applies on load (saves a 20 Nz pass)
-    bool bpend = false;
-    double bmul = 1.0, bdiv = 1.0;
-    bool zp_pend = false;            // the op that was pending on the kept beta^k (beta2) when it was read
-    double zp_mul = 1.0, zp_div = 1.0;
+    int bpend = 0;           // pending operations on beta: 0, 1 or 2 (x * bmul / bdiv, then x * bmul2 / bdiv2)
+    double bmul = 1.0, bdiv = 1.0, bmul2 = 1.0, bdiv2 = 1.0;
+    int push_beta_op(double mul, double div);
+    int zp_pend = 0;                 // the ops that were pending on the kept beta^k (beta2) when it was read
+    double zp_mul = 1.0, zp_div = 1.0, zp_mul2 = 1.0, zp_div2 = 1.0;
+    // KKT sums of the last check (Solver::kkt_block) and the sigma they were taken with: the rescale block of the
+    // NEXT iteration finds its five norms there instead of making its own passes over the state
+    double last_S[S_COUNT] = {0};
+    double last_S_sigma = 1.0;
+    i64 last_S_it = -1;
     int flush_beta();
     // same for alpha after a sigma update on the folded KKT path: the next q-step divides on load
     bool apend = false;
     double amul = 1.0, adiv = 1.0;
     int flush_alpha();
     int sigma_scale_folded(double factor);
+    bool norm_cache = true;  // DOTSOCP_NORM_CACHE=0: the rescale block always makes its own passes for its norms
     bool kkt_fold = true;    // DOTSOCP_KKT_FOLD=0: KKT sums by the separate node / edge launches on every path
     KktCoef kkt_coef() const;
-    void set_pending(FusedArgs &a) const { a.bpend = bpend ? 1 : 0; a.bmul = bmul; a.bdiv = bdiv; }
+    void set_pending(FusedArgs &a) const {
+        a.bpend = bpend; a.bmul = bmul; a.bdiv = bdiv; a.bmul2 = bmul2; a.bdiv2 = bdiv2;
+    }
     struct Pending { hipEvent_t a, b; int phase; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;

@@ -261,6 +261,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs, bool multi_dev) 
     if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_QRHS")) qrhs = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_KKT_FOLD")) kkt_fold = (atoi(e) != 0);
+    if (const char *e = getenv("DOTSOCP_NORM_CACHE")) norm_cache = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_TSOLVE")) tri_tsolve = (strcmp(e, "dct") != 0);
     DS_HIP(hipHostMalloc((void **)&h_sums, sizeof(double) * (S_COUNT + 1)));
     DS_CHECK(dmalloc(&d_red, S_COUNT + 1));
@@ -327,7 +328,7 @@ int Solver::alloc_slabs(int first, int count) {
         }
         s.kw.maxBlocks = kkt_partials_needed(g);
         DS_CHECK(dzalloc(&s.kw.partials, s.kw.maxBlocks * S_COUNT, s.st));
-        DS_CHECK(dmalloc(&s.kw.sums, S_COUNT));
+        DS_CHECK(dmalloc(&s.kw.sums, S_COUNT * (1 + KKT_SLICES)));
         pencil_range(plane, world, s.index, &s.l0, &s.nl);
         s.nl -= s.l0;
         if (multi()) {
@@ -841,8 +842,20 @@ void Solver::update_coef() {
 
 int Solver::flush_beta() {
     if (!bpend) return 0;
-    FOR_SLABS(s) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul, bdiv, s.st));
-    bpend = false;
+    FOR_SLABS(s) {
+        DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul, bdiv, s.st));
+        if (bpend > 1) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul2, bdiv2, s.st));
+    }
+    bpend = 0;
+    return 0;
+}
+
+// beta <- beta * mul / div, executed by the next pass that reads beta (two operations can wait)
+int Solver::push_beta_op(double mul, double div) {
+    if (bpend >= 2) DS_CHECK(flush_beta());
+    if (bpend == 0) { bmul = mul; bdiv = div; }
+    else { bmul2 = mul; bdiv2 = div; }
+    bpend += 1;
     return 0;
 }
 
@@ -858,9 +871,8 @@ int Solver::flush_alpha() {
 // reader (cone pass resp. q-step), and the right-hand side of the next phi-step is corrected with the r = A' alpha - c
 // the q-step stored: A'(w.*q - alpha / f) + c / f = (rhs + r) - r / f.  c is divided in that same small pass.
 int Solver::sigma_scale_folded(double factor) {
-    DS_CHECK(flush_beta());
     DS_CHECK(flush_alpha());
-    bpend = true; bmul = 1.0; bdiv = factor;
+    DS_CHECK(push_beta_op(1.0, factor));
     apend = true; amul = 1.0; adiv = factor;
     u0_fresh = false;
     FOR_SLABS(s) DS_CHECK(launch_rhs_sigma_fix(s.w0, s.w1, s.c, s.g.Nphi, factor, s.st));
@@ -872,11 +884,8 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
     u0_fresh = false;      // q0 / alpha0 change: the u0 tail held by the right neighbour is stale
     rhs_valid = false;     // ... and so is the right-hand side the last q-step left in w0
     if (fused && begun) {
-        // beta: applied by the next pass that reads it (one op can be pending at a time)
-        DS_CHECK(flush_beta());
-        bpend = true;
-        bmul = a_mul;
-        bdiv = a_div;
+        // beta: applied by the next pass that reads it
+        DS_CHECK(push_beta_op(a_mul, a_div));
     }
     FOR_SLABS(s) {
         const Grid &g = s.g;
@@ -885,9 +894,12 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
         if (!(fused && begun)) DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, s.st));
         if (q_div != 1.0) {
             DS_CHECK(launch_scale(s.q, g.NqAlloc, 1.0, q_div, s.st));
-            DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, s.st));
+            // fused dataflow: a z that is not materialised is not scaled either -- it is regenerated from the scaled
+            // q and beta when somebody asks for it (the kept beta^k / q^k pair of the last KKT pass no longer matches)
+            if (!(fused && begun) || z_valid) DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, s.st));
         }
     }
+    if (q_div != 1.0 && fused && begun && !z_valid) z_prev_ok = false;
     return 0;
 }
 
@@ -938,6 +950,7 @@ int Solver::begin(const dotsocp_opts *o) {
     z_valid = true;
     z_prev_ok = false;
     rhs_valid = false;
+    last_S_it = -1;
     hist_kkt.clear(); hist_time.clear(); hist_iter.clear(); hist_gap.clear();
     for (int i = 0; i < PH_COUNT; ++i) { phase_ms[i] = 0; phase_launches[i] = 0; }
     if (canary_enabled() && getenv("DOTSOCP_CANARY_SELFTEST")) {
@@ -1063,7 +1076,7 @@ int Solver::phase_z(bool on_z, int part) {
     }
     if (part == 1) return 0;
     prof_end(ph, on_z);
-    if (deferred) bpend = false;      // mode B rewrote beta with the scaling applied
+    if (deferred) bpend = 0;          // mode B rewrote beta with the scaling applied
     return 0;
 }
 
@@ -1177,7 +1190,7 @@ int Solver::materialise() {
         DS_CHECK(launch_cone_fused(2, s.g, lc, s.fg, a, s.st));
     }
     prof_end(PH_MATERIALISE);
-    bpend = false;
+    bpend = 0;
     deferred = false;
     z_valid = true;
     return 0;
@@ -1199,9 +1212,8 @@ int Solver::ensure_z() {
         a.q = s.q;
         a.beta_in = s.beta2;      // beta^k, kept by the KKT pass
         a.z_out = s.z;
-        a.bpend = zp_pend ? 1 : 0;
-        a.bmul = zp_mul;
-        a.bdiv = zp_div;
+        a.bpend = zp_pend;
+        a.bmul = zp_mul; a.bdiv = zp_div; a.bmul2 = zp_mul2; a.bdiv2 = zp_div2;
         DS_CHECK(launch_cone_fused(3, s.g, lc, s.fg, a, s.st));
     }
     prof_end(PH_MATERIALISE);
@@ -1237,8 +1249,8 @@ int Solver::kkt_sums(double *S, bool folded) {
             std::swap(s.beta, s.beta2);
         }
         // the kept beta^k (now in beta2) is still unscaled in memory: remember its pending op for MODE_Z
-        zp_pend = bpend; zp_mul = bmul; zp_div = bdiv;
-        bpend = false;
+        zp_pend = bpend; zp_mul = bmul; zp_div = bdiv; zp_mul2 = bmul2; zp_div2 = bdiv2;
+        bpend = 0;
         deferred = false;
         z_valid = false;
         z_prev_ok = true;
@@ -1298,12 +1310,21 @@ int Solver::rescale_block() {
     double normPhis = 0, normAlps = 0;
     auto norms = [&](double &nPhis, double &nAlps) -> int {
         double S[S_COUNT + 1];
-        DS_CHECK(materialise());
-        DS_CHECK(ensure_z());
-        DS_CHECK(kkt_sums(S));
+        double sig = sigma;
+        if (method == DOTSOCP_METHOD_INPALM && fused && last_S_it == it - 1 && norm_cache) {
+            // The previous iteration ended with a KKT check: its sums ARE the squared norms of phi, q, z, alpha, beta
+            // of the current iterate.  A sigma update in between divided alpha and beta by `factor` and multiplied
+            // sigma by it, so sigma * ||alpha|| is what it was with the sigma of the check -- no pass over the state.
+            for (int i = 0; i < S_COUNT; ++i) S[i] = last_S[i];
+            sig = last_S_sigma;
+        } else {
+            DS_CHECK(materialise());
+            DS_CHECK(ensure_z());
+            DS_CHECK(kkt_sums(S));
+        }
         const double sh = sqrt(h);
         const double normPhi = sh * sqrt(S[S_PHI2]), normQ = sh * sqrt(S[S_Q2]), normZ = sh * sqrt(S[S_Z2]);
-        const double normAlpha = sigma * (sh * sqrt(S[S_ALPHA2])), normBeta = sigma * (sh * sqrt(S[S_BETA2]));
+        const double normAlpha = sig * (sh * sqrt(S[S_ALPHA2])), normBeta = sig * (sh * sqrt(S[S_BETA2]));
         nPhis = std::max(std::max(normPhi, normQ), normZ);
         nAlps = std::max(normAlpha, normBeta);
         return 0;
@@ -1377,6 +1398,9 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk, bool folde
     // one slab per process: the ranks must take the time-limit decision together, so it is taken
     // here from the maximum of their wall clocks (time-outs are detected at KKT checks only)
     if (remote()) timed_out = elapsed_agreed > time_limit;
+    for (int i = 0; i < S_COUNT; ++i) last_S[i] = S[i];
+    last_S_sigma = sigma;
+    last_S_it = it;
     const double sh = sqrt(h);
     auto nrm = [&](int i) { return sh * sqrt(S[i]); };
     const double norm_q = nrm(S_Q2), norm_z = nrm(S_Z2), norm_Aphi = nrm(S_APHI2);

@@ -62,7 +62,7 @@ int Solver::palm_step(bool *brk) {
             DS_CHECK(launch_cone_fused(4, s.g, lc, s.fg, a, s.st));
             std::swap(s.beta, s.beta2);
         }
-        bpend = false;
+        bpend = 0;
         deferred = false;
     } else {
         DS_CHECK(ensure_z());             // first iteration, or right after a KKT / rescale block

@@ -321,6 +321,40 @@ __device__ __forceinline__ double q_value(const LoopCoef &c, double tmp, double 
     return a;
 }
 
+// q_value on operands that are already in registers (the q-step's load phase): a = alpha_in[k], w = weight[k]
+template <bool WEIGHTED, int MULT = 0>
+__device__ __forceinline__ double q_calc(const LoopCoef &c, double tmp, double q2, double diag_c, double dinv, double w,
+                                         double a, const APend &ap, double &qn, double &an, double &u) {
+    if (ap.on) a = a * ap.mul / ap.div;
+    if (WEIGHTED) {
+        const double di = 1.0 / (diag_c + w * w);
+        qn = (w * (tmp + a) + q2) * di;
+        if (MULT == 2) {
+            an = a;
+        } else if (MULT == 1) {
+            const double t = a + tmp;                 // alpha + tmp_q - w.*q (solver_wsocp_accADMM.m:243)
+            an = t - w * qn;
+        } else {
+            const double r = tmp - w * qn;
+            an = a + c.tau * r;
+        }
+        u = w * qn - an;
+    } else {
+        qn = (tmp + a + q2) * dinv;
+        if (MULT == 2) {
+            an = a;
+        } else if (MULT == 1) {
+            const double t = a + tmp;                 // alpha + tmp_q - q (solver_socp_accADMM.m:237)
+            an = t - qn;
+        } else {
+            const double r = tmp - qn;
+            an = a + c.tau * r;
+        }
+        u = qn - an;
+    }
+    return a;
+}
+
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
@@ -350,8 +384,8 @@ struct QRhsArgs {
 // sigma update the right-hand side of the next phi-step is rhs + r - r / factor (launch_rhs_sigma_fix) instead of a new pass.
 enum { Q_Q2 = 0, Q_ALPHA2, Q_APHI2, Q_PRIM1, Q_QALPHA, Q_CPHI, Q_PHI2, Q_DUAL1, Q_MRHOB, Q_M2, Q_RHOB2, Q_COUNT };
 
-template <bool WEIGHTED, int VAR, bool KKT = false>
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
+template <bool WEIGHTED, int VAR, bool KKT = false, int OCC = 1>
+__global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
     __shared__ double xch[2][TILE_X][TILE_Y];
     __shared__ double xcha[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // alpha^+ of the bx edge
     __shared__ double xchr[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // density at the node
@@ -378,18 +412,6 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     const bool inb = (y < g.ny) && (x < g.nx);
     const i64 t0 = ((i64)blockIdx.z * a.zstride + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ntl) ? t0 + a.TC : g.ntl;
-    auto bx_q2 = [&](i64 yy, i64 xx, i64 tl, i64 e) {
-        double q2 = a.q2v[e];
-        if ((xx % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + a.sx[(tl * fg.nxblk + (xx / fg.XB + 1)) * g.ny + yy]);
-        if (tl == 0 && !g.first) q2 += a.tail_bx[yy + g.ny * xx];
-        return q2;
-    };
-    auto by_q2 = [&](i64 yy, i64 xx, i64 tl, i64 e) {
-        double q2 = a.q2v[e];
-        if ((yy & 63) == 63) q2 = c.sf * (q2 + a.sy[(tl * g.nx + xx) * fg.nyblk + (yy / 64 + 1)]);
-        if (tl == 0 && !g.first) q2 += a.tail_by[yy + (g.ny - 1) * xx];
-        return q2;
-    };
     auto put = [&](i64 k, double qn, double an, double ain) {
         a.q_out[k] = qn;
         if (VAR == 3) return;                         // PALM's first q-step: alpha is not touched
@@ -421,63 +443,140 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
             }
         }
     }
+    // The march.  Every step is written in three phases -- all loads of the step (from clamped, always valid
+    // addresses; the few that exist on tile / slab borders only sit under their condition but are loads and nothing
+    // else), then the arithmetic, then the stores -- so that the loads leave together and are waited for once.  (With
+    // a load, its use and a store inside one `if` per entry the step was five dependent memory round trips long.)
+    constexpr int MULT = (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0));
+    const i64 yc = inb ? y : 0, xc = inb ? x : 0;
+    const bool hasBx = inb && (x < g.nx - 1), hasBy = inb && (y < g.ny - 1);
+    const bool leftTile = inb && (xl == 0) && (x >= 1);          // the bx edge on the left belongs to the tile there
+    const bool belowTile = inb && (lane == 0) && (y >= 1);       // the by edge below belongs to the tile there
+    const bool sxOwn = hasBx && ((x % fg.XB) == fg.XB - 1), syOwn = hasBy && ((y & 63) == 63);
     int par = 0;
     for (i64 tl = t0; tl < t1; ++tl) {
-        const i64 node = y + g.ny * (x + g.nx * tl);
+        const i64 node = yc + g.ny * (xc + g.nx * tl);
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
         const double dc = tbnd ? c.c2 : c.c1;
         const double di = tbnd ? c.dinv2 : c.dinv1;
+        const bool hasCell = inb && (tl < g.ncl);
+        const bool tails = (tl == 0) && !g.first;                // slab mode: the left neighbour's share of the first layer
+        // ---------------- loads ----------------
+        const i64 eX = hasBx ? g.offBx + g.bxLayer * tl + yc + g.ny * xc : node;
+        const i64 eY = hasBy ? g.offBy + g.byLayer * tl + yc + (g.ny - 1) * xc : node;
+        const i64 k0 = hasCell ? node : 0;                       // q0 entries exist for tl < ncl only
+        const double pTl = a.phi[hasCell ? node + g.plane : node];
+        const double pXl = a.phi[hasBx ? node + g.ny : node];
+        const double pYl = a.phi[hasBy ? node + 1 : node];
+        const double al0 = a.alpha_in[k0], alX = a.alpha_in[eX], alY = a.alpha_in[eY];
+        const double g0 = a.q2v[k0];
+        double gX = a.q2v[eX], gY = a.q2v[eY];
+        const double cv = a.cvec[node];
+        double w0 = 1.0, wX = 1.0, wY = 1.0;
+        if (WEIGHTED) { w0 = a.weight[k0]; wX = a.weight[eX]; wY = a.weight[eY]; }
+        const double sxv = a.sx[sxOwn ? (tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y : 0];
+        const double syv = a.sy[syOwn ? (tl * g.nx + x) * fg.nyblk + (y / 64 + 1) : 0];
+        double tXv = 0.0, tYv = 0.0;
+        if (tails) {
+            if (hasBx) tXv = a.tail_bx[y + g.ny * x];
+            if (hasBy) tYv = a.tail_by[y + (g.ny - 1) * x];
+        }
+        // neighbour tiles' edges (first column / first row of the tile)
+        double pLl = 0.0, alL = 0.0, gL = 0.0, wL = 1.0, sxL = 0.0, tLv = 0.0;
+        i64 eL = 0;
+        if (leftTile) {
+            eL = g.offBx + g.bxLayer * tl + y + g.ny * (x - 1);
+            pLl = a.phi[node - g.ny];
+            alL = a.alpha_in[eL];
+            gL = a.q2v[eL];
+            if (WEIGHTED) wL = a.weight[eL];
+            if (((x - 1) % fg.XB) == fg.XB - 1) sxL = a.sx[(tl * fg.nxblk + ((x - 1) / fg.XB + 1)) * g.ny + y];
+            if (tails) tLv = a.tail_bx[y + g.ny * (x - 1)];
+        }
+        double pBl = 0.0, alB = 0.0, gB = 0.0, wB = 1.0, syB = 0.0, tBv = 0.0;
+        i64 eB = 0;
+        if (belowTile) {
+            eB = g.offBy + g.byLayer * tl + (y - 1) + (g.ny - 1) * x;
+            pBl = a.phi[node - 1];
+            alB = a.alpha_in[eB];
+            gB = a.q2v[eB];
+            if (WEIGHTED) wB = a.weight[eB];
+            if (((y - 1) & 63) == 63) syB = a.sy[(tl * g.nx + x) * fg.nyblk + ((y - 1) / 64 + 1)];
+            if (tails) tBv = a.tail_by[(y - 1) + (g.ny - 1) * x];
+        }
+        // ---------------- arithmetic ----------------
+        // the adjoint sums of an edge on a tile border are completed from the neighbour tile's partial (k_qstep_fused)
+        if (sxOwn) gX = c.sf * (gX + sxv);
+        if (syOwn) gY = c.sf * (gY + syv);
+        if (tails) { gX += tXv; gY += tYv; }
         double pT = 0.0, u0 = 0.0, ubx = 0.0, uby = 0.0;
         double a0 = 0.0, abx = 0.0, aby = 0.0;                 // KKT: alpha^+ of the own entries
         double qbx = 0.0, mbx = 0.0, qby = 0.0, mby = 0.0;     // KKT: q^+ and momentum kappa (w alpha^+) of the own edges
         double rhoT = 0.0;                                     // KKT: density of the cell that starts at this node
-        if (inb) {
-            double qn, an;
-            if (tl < g.ncl) {
-                pT = a.phi[node + g.plane];
-                double tmp = (-c.at) * p0;
-                tmp += c.at * pT;
-                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[node], c.c1, c.dinv1, node, a.weight, a.alpha_in, qn, an, u0, a.ap);
-                put(node, qn, an, ain);
-                if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
-                if (KKT) {
-                    const double w = wgt(node);
-                    entry(tmp, qn, an, w);
-                    a0 = an;
-                    rhoT = a.kappa * (w * an);
-                }
-            }
-            if (x < g.nx - 1) {
-                const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
-                double tmp = (-c.ax) * p0;
-                tmp += c.ax * a.phi[node + g.ny];
-                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx, a.ap);
-                put(e, qn, an, ain);
-                if (KKT) {
-                    const double w = wgt(e);
-                    entry(tmp, qn, an, w);
-                    abx = an;
-                    qbx = qn;
-                    mbx = a.kappa * (w * an);
-                    S[Q_M2] += mbx * mbx;
-                }
-            }
-            if (y < g.ny - 1) {
-                const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
-                double tmp = (-c.ay) * p0;
-                tmp += c.ay * a.phi[node + 1];
-                const double ain = q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby, a.ap);
-                put(e, qn, an, ain);
-                if (KKT) {
-                    const double w = wgt(e);
-                    entry(tmp, qn, an, w);
-                    aby = an;
-                    qby = qn;
-                    mby = a.kappa * (w * an);
-                    S[Q_M2] += mby * mby;
-                }
+        double q0n = 0.0, a0n = 0.0, ain0 = 0.0, qXn = 0.0, aXn = 0.0, ainX = 0.0, qYn = 0.0, aYn = 0.0, ainY = 0.0;
+        if (hasCell) {
+            pT = pTl;
+            double tmp = (-c.at) * p0;
+            tmp += c.at * pT;
+            ain0 = q_calc<WEIGHTED, MULT>(c, tmp, g0, c.c1, c.dinv1, w0, al0, a.ap, q0n, a0n, u0);
+            if (KKT) {
+                entry(tmp, q0n, a0n, w0);
+                a0 = a0n;
+                rhoT = a.kappa * (w0 * a0n);
             }
         }
+        if (hasBx) {
+            double tmp = (-c.ax) * p0;
+            tmp += c.ax * pXl;
+            ainX = q_calc<WEIGHTED, MULT>(c, tmp, gX, dc, di, wX, alX, a.ap, qXn, aXn, ubx);
+            if (KKT) {
+                entry(tmp, qXn, aXn, wX);
+                abx = aXn;
+                qbx = qXn;
+                mbx = a.kappa * (wX * aXn);
+                S[Q_M2] += mbx * mbx;
+            }
+        }
+        if (hasBy) {
+            double tmp = (-c.ay) * p0;
+            tmp += c.ay * pYl;
+            ainY = q_calc<WEIGHTED, MULT>(c, tmp, gY, dc, di, wY, alY, a.ap, qYn, aYn, uby);
+            if (KKT) {
+                entry(tmp, qYn, aYn, wY);
+                aby = aYn;
+                qby = qYn;
+                mby = a.kappa * (wY * aYn);
+                S[Q_M2] += mby * mby;
+            }
+        }
+        double ubx_l = 0.0, abx_l = 0.0, uby_b = 0.0, aby_b = 0.0;
+        if (leftTile) {
+            double q2 = gL;
+            if (((x - 1) % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sxL);
+            if (tails) q2 += tLv;
+            double tmp = (-c.ax) * pLl;
+            tmp += c.ax * p0;
+            double qn, an;
+            q_calc<WEIGHTED, MULT>(c, tmp, q2, dc, di, wL, alL, a.ap, qn, an, ubx_l);
+            abx_l = an;
+        }
+        if (belowTile) {
+            double q2 = gB;
+            if (((y - 1) & 63) == 63) q2 = c.sf * (q2 + syB);
+            if (tails) q2 += tBv;
+            double tmp = (-c.ay) * pBl;
+            tmp += c.ay * p0;
+            double qn, an;
+            q_calc<WEIGHTED, MULT>(c, tmp, q2, dc, di, wB, alB, a.ap, qn, an, uby_b);
+            aby_b = an;
+        }
+        // ---------------- stores ----------------
+        if (hasCell) {
+            put(node, q0n, a0n, ain0);
+            if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
+        }
+        if (hasBx) put(eX, qXn, aXn, ainX);
+        if (hasBy) put(eY, qYn, aYn, ainY);
         // density at the node: mean of the two cells that meet there in time, zero outside (movmean's padding)
         const double rhoN = (rhoTprev + rhoT) / 2.0;
         xch[par][xl][lane] = ubx;
@@ -496,21 +595,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                     ubx_m = xch[par][xl - 1][lane];
                     if (KKT) abx_m = xcha[par][xl - 1][lane];
                 } else {            // edge owned by the tile to the left
-                    const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * (x - 1);
-                    double tmp = (-c.ax) * a.phi[node - g.ny];
-                    tmp += c.ax * p0;
-                    double qn, an;
-                    q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, bx_q2(y, x - 1, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, ubx_m, a.ap);
-                    abx_m = an;
+                    ubx_m = ubx_l;
+                    abx_m = abx_l;
                 }
             }
-            if (y >= 1 && lane == 0) {      // edge owned by the tile below
-                const i64 e = g.offBy + g.byLayer * tl + (y - 1) + (g.ny - 1) * x;
-                double tmp = (-c.ay) * a.phi[node - 1];
-                tmp += c.ay * p0;
-                double qn, an;
-                q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, by_q2(y - 1, x, tl, e), dc, di, e, a.weight, a.alpha_in, qn, an, uby_m, a.ap);
-                aby_m = an;
+            if (belowTile) {        // edge owned by the tile below
+                uby_m = uby_b;
+                aby_m = aby_b;
             }
             double r = 0.0;
             if (tl >= 1) r += c.at * u0prev;
@@ -519,7 +610,6 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
             if (x <= g.nx - 2) r += (-c.ax) * ubx;
             if (y >= 1) r += c.ay * uby_m;
             if (y <= g.ny - 2) r += (-c.ay) * uby;
-            const double cv = a.cvec[node];
             a.rhs[node] = r + cv;
             if (KKT) {
                 double ra = 0.0;                       // A' alpha^+ in the order of k_kkt's node part
@@ -677,8 +767,14 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     dim3 blk(TILE_Y, TILE_X);
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
     if (var == 0 && a.partials) {          // iteration with a KKT check
-        if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
-        else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
+        static const int occ = getenv("DOTSOCP_KKT_OCC") ? atoi(getenv("DOTSOCP_KKT_OCC")) : 0;
+        if (occ) {
+            if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true, 4>), grid, blk, 0, st, g, c, fg, a);
+            else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true, 4>), grid, blk, 0, st, g, c, fg, a);
+        } else {
+            if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
+            else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
+        }
     } else if (a.weight) {
         if (var == 0) QRHS_LAUNCH(true, 0); else if (var == 1) QRHS_LAUNCH(true, 1); else QRHS_LAUNCH(true, 2);
     } else {
