@@ -100,7 +100,9 @@ int launch_bfd(const Grid &g, double *z, const double *q, double s, double dF, h
 
 // seg: 0 = q0 (cells), 1 = bx edges, 2 = by edges
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd_conj(Grid g, double *__restrict__ q, const double *__restrict__ w,
-                                                              double s, double sf, int seg) {
+                                                              double s, double sf, int seg,
+                                                              const double *__restrict__ tail_bx,
+                                                              const double *__restrict__ tail_by) {
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
@@ -111,18 +113,24 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd_conj(Grid g, double *__r
         q[i] = s * (w[9 * g.Nz + i] - w[i]);
     } else if (seg == 1) {
         if (y >= g.ny || x >= g.nx - 1) return;
-        q[g.offBx + g.bxLayer * tl + y + g.ny * x] = sf * gather_bx(g, W, y, x, tl, nullptr);
+        q[g.offBx + g.bxLayer * tl + y + g.ny * x] = sf * gather_bx(g, W, y, x, tl, tail_bx);
     } else {
         if (y >= g.ny - 1 || x >= g.nx) return;
-        q[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x] = sf * gather_by(g, W, y, x, tl, nullptr);
+        q[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x] = sf * gather_by(g, W, y, x, tl, tail_by);
     }
 }
 
-int launch_bfd_conj(const Grid &g, double *q, const double *w, double s, hipStream_t st) {
+int launch_bfd_conj(const Grid &g, double *q, const double *w, double s, hipStream_t st, const double *tail_bx,
+                    const double *tail_by) {
     const double sf = s / sqrt(2.0);
-    if (g.Nz > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ncl), dim3(TILE_Y, TILE_X), 0, st, g, q, w, s, sf, 0);
-    if (g.bxLayer > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, q, w, s, sf, 1);
-    if (g.byLayer > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, q, w, s, sf, 2);
+    if (!g.first && (!tail_bx || !tail_by)) {
+        set_error("bfd_conj on a time slab needs the left neighbour's tails");
+        return DOTSOCP_EINVAL;
+    }
+    const dim3 blk(TILE_Y, TILE_X);
+    if (g.Nz > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ncl), blk, 0, st, g, q, w, s, sf, 0, tail_bx, tail_by);
+    if (g.bxLayer > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ntl), blk, 0, st, g, q, w, s, sf, 1, tail_bx, tail_by);
+    if (g.byLayer > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ntl), blk, 0, st, g, q, w, s, sf, 2, tail_bx, tail_by);
     DS_HIP(hipGetLastError());
     return 0;
 }

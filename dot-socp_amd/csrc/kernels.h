@@ -32,7 +32,10 @@ struct KktCoef {
 // ---------------- cone.hip ----------------
 int launch_proj_soc(double *out, const double *in, i64 M, i64 K, hipStream_t st);
 int launch_bfd(const Grid &g, double *z, const double *q, double s, double dF, hipStream_t st);
-int launch_bfd_conj(const Grid &g, double *q, const double *w, double s, hipStream_t st);
+// tail_bx / tail_by (time slabs, not the first): raw partial sums w4(x+1) + w5(x) resp. w8(y+1) + w9(y) of the left
+// neighbour's last cell layer (launch_kkt_tail's bt_bx / bt_by)
+int launch_bfd_conj(const Grid &g, double *q, const double *w, double s, hipStream_t st, const double *tail_bx = nullptr,
+                    const double *tail_by = nullptr);
 // z = Pi_Q(B F q + d - beta), B F q + d regenerated from q on the fly (solver_socp_inPALM.m:199)
 int launch_cone_proj(const Grid &g, const LoopCoef &c, const double *q, const double *beta, double *z,
                      hipStream_t st);
@@ -102,10 +105,12 @@ int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const Acc
                       hipStream_t st);
 
 // ---------------- transfer.hip (driver steps on the device) ----------------
+// gf: the fine slab; phic / betac hold the coarse layers tc0, tc0 + 1, ... (a single coarse slab: its own arrays, tc0 = 0;
+// Nzc = doubles per cone column in betac, < 0: gc.Nz); gc is read for ny, nx only
 int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, double *phif, double sc_in, double sc_out,
-                       hipStream_t st);
+                       hipStream_t st, i64 tc0 = 0);
 int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, double *betaf, double *neg, double sc_in0,
-                        double sc_in1, double sc_out, hipStream_t st);
+                        double sc_in1, double sc_out, hipStream_t st, i64 tc0 = 0, i64 Nzc = -1);
 int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t st);
 // slab-aware: `out` holds the slab's own layers (ntl node layers resp. ncl cell layers); a_prev: launch_out_tail of the
 // left neighbour (nullptr on the first slab)

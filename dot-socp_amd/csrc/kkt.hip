@@ -395,6 +395,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_kkt_cells(Grid g, LoopC
 // node and the x+1 cells of their adjoint gather live in the next tile; DIR 1: by edges (y+1/2, x, t) with y % 64 == 63.
 // Per edge: the momentum terms the q-step's KKT variant left out, and ||F*B*beta||^2, ||F*B*beta + w.*alpha||^2 from the raw
 // partial sums k_kkt_cells<., true> left in q2 / sx / sy.  alpha, q: the new iterates in memory.
+#define BND_TC 8
 template <bool WEIGHTED, int DIR>
 __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, FusedGeom fg, const double *__restrict__ q,
                                                   const double *__restrict__ alpha, const double *__restrict__ weight,
@@ -408,9 +409,11 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
     };
     auto rho_node = [&](i64 yy, i64 xx, i64 tl) { return (rhoT_at(yy, xx, tl - 1) + rhoT_at(yy, xx, tl)) / 2.0; };
     double sM = 0.0, sR = 0.0, sF = 0.0, sD = 0.0;
-    // DIR 0: threads along y, blockIdx.y = border column; DIR 1: threads along x, blockIdx.y = border row
+    // DIR 0: threads along y, blockIdx.y = border column; DIR 1: threads along x, blockIdx.y = border row;
+    // blockIdx.z: a chunk of BND_TC edge layers
     const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
-    const i64 tl = blockIdx.z;
+    const i64 tbeg = (i64)blockIdx.z * BND_TC, tend = (tbeg + BND_TC < g.ntl) ? tbeg + BND_TC : g.ntl;
+    for (i64 tl = tbeg; tl < tend; ++tl) {
     if (DIR == 0) {
         const i64 y = u, x = (i64)blockIdx.y * TILE_X + (TILE_X - 1);
         if (y < g.ny && x < g.nx - 1) {
@@ -419,12 +422,12 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
             const double rb = k.dsD * (rm * q[e]);
             const double m = k.kappa * (wgt(e) * alpha[e]);
             const double d = m - rb;
-            sM = d * d;
-            sR = rb * rb;
+            sM += d * d;
+            sR += rb * rb;
             const double gb = c.sf * (q2[e] + sx[(tl * fg.nxblk + (x / TILE_X + 1)) * g.ny + y]);
-            sF = gb * gb;
+            sF += gb * gb;
             const double r2 = gb + wgt(e) * alpha[e];
-            sD = r2 * r2;
+            sD += r2 * r2;
         }
     } else {
         const i64 x = u, y = (i64)blockIdx.y * 64 + 63;
@@ -434,13 +437,14 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
             const double rb = k.dsD * (rm * q[e]);
             const double m = k.kappa * (wgt(e) * alpha[e]);
             const double d = m - rb;
-            sM = d * d;
-            sR = rb * rb;
+            sM += d * d;
+            sR += rb * rb;
             const double gb = c.sf * (q2[e] + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
-            sF = gb * gb;
+            sF += gb * gb;
             const double r2 = gb + wgt(e) * alpha[e];
-            sD = r2 * r2;
+            sD += r2 * r2;
         }
+    }
     }
     __shared__ double red[4][4];
     double v4[4] = {sM, sR, sF, sD};
@@ -501,8 +505,9 @@ static void kkt_geometry(const Grid &g, dim3 &grid, i64 &chunk) {
 }
 
 static i64 bnd_blocks(const Grid &g, const FusedGeom &fg, int dir) {
-    if (dir == 0) return ((g.ny + 255) / 256) * fg.nxblk * g.ntl;
-    return ((g.nx + 255) / 256) * fg.nyblk * g.ntl;
+    const i64 tch = (g.ntl + BND_TC - 1) / BND_TC;
+    if (dir == 0) return ((g.ny + 255) / 256) * fg.nxblk * tch;
+    return ((g.nx + 255) / 256) * fg.nyblk * tch;
 }
 
 static i64 kkt_region_blocks(const Grid &g) {
@@ -575,7 +580,7 @@ int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, 
     for (int dir = 0; dir < 2; ++dir) {
         const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;
         if (len <= 0 || lines <= 0) continue;
-        dim3 gb((unsigned)((len + 255) / 256), (unsigned)lines, (unsigned)g.ntl);
+        dim3 gb((unsigned)((len + 255) / 256), (unsigned)lines, (unsigned)((g.ntl + BND_TC - 1) / BND_TC));
         double *pb = w.partials + (2 + dir) * region * S_COUNT;
 #define BND(W, D) hipLaunchKernelGGL((k_kkt_bnd<W, D>), gb, dim3(256), 0, st, g, c, k, fg, q_new, alpha, weight, a.q2, a.sx, a.sy, pb)
         if (weight) { if (dir == 0) BND(true, 0); else BND(true, 1); }

@@ -27,37 +27,40 @@ __device__ __forceinline__ double interp_yx(const F &f, i64 yf, i64 xf) {
 }
 
 // phi_f = sc_out * interp(sc_in * phi_c)
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_phi(i64 nyf, i64 nxf, i64 ntf, i64 nyc, i64 nxc,
+// Time slabs: blockIdx.z is the slab-local fine layer, t0f + blockIdx.z the global one; `phic` holds the coarse layers
+// tc0, tc0 + 1, ... (gathered from the coarse slabs that own them).
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_phi(i64 nyf, i64 nxf, i64 t0f, i64 tc0, i64 nyc, i64 nxc,
                                                                  const double *__restrict__ phic,
                                                                  double *__restrict__ phif, double sc_in,
                                                                  double sc_out) {
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
-    const i64 t = blockIdx.z;
+    const i64 tloc = blockIdx.z, t = t0f + tloc;
     if (y >= nyf || x >= nxf) return;
     const i64 planec = nyc * nxc;
-    const i64 tc = t >> 1;
+    const i64 tc = (t >> 1) - tc0;
     auto layer = [&](i64 tt) {
         const double *p = phic + planec * tt;
         return interp_yx([&](i64 yc, i64 xc) { return sc_in * p[yc + nyc * xc]; }, y, x);
     };
     double v = layer(tc);
     if (t & 1) v = (v + layer(tc + 1)) / 2;
-    phif[y + nyf * (x + nxf * t)] = sc_out * v;
-    (void)ntf;
+    phif[y + nyf * (x + nxf * tloc)] = sc_out * v;
 }
 
 // per cone column: betaR = interp(sc_in1 * (sc_in0 * beta_c)) ; beta_f = sc_out * betaR ; neg = -betaR
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_beta(i64 nyf, i64 nxf, i64 nclf, i64 nyc, i64 nxc, i64 Nzc,
+// (time slabs as in k_prolong_phi: t0f = global index of the slab's first fine cell, `betac` holds the coarse cell
+// layers tc0, tc0 + 1, ... of every cone column, Nzc doubles per column)
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_beta(i64 nyf, i64 nxf, i64 t0f, i64 tc0, i64 nyc, i64 nxc, i64 Nzc,
                                                                   i64 Nzf, const double *__restrict__ betac,
                                                                   double *__restrict__ betaf, double *__restrict__ neg,
                                                                   double sc_in0, double sc_in1, double sc_out) {
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
-    const i64 t = blockIdx.z;                 // fine cell index
+    const i64 tloc = blockIdx.z;              // slab-local fine cell
     if (y >= nyf || x >= nxf) return;
-    const i64 tc = t >> 1;                    // interpolate.m:73-84: fR(:, :, oddT) = fR(:, :, evenT) = f
-    const i64 i = y + nyf * (x + nxf * t);
+    const i64 tc = ((t0f + tloc) >> 1) - tc0; // interpolate.m:73-84: fR(:, :, oddT) = fR(:, :, evenT) = f
+    const i64 i = y + nyf * (x + nxf * tloc);
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
         const double *p = betac + j * Nzc + nyc * nxc * tc;
@@ -65,7 +68,6 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_beta(i64 nyf, i64 nx
         betaf[j * Nzf + i] = sc_out * v;
         neg[j * Nzf + i] = -v;
     }
-    (void)nclf;
 }
 
 // x = sc * x ./ w  (w == nullptr: x = sc * x)
@@ -78,19 +80,21 @@ __global__ void __launch_bounds__(256) k_scale_div(double *__restrict__ x, const
 }
 
 int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, double *phif, double sc_in, double sc_out,
-                       hipStream_t st) {
+                       hipStream_t st, i64 tc0) {
+    if (gf.ntl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ntl);
-    hipLaunchKernelGGL(k_prolong_phi, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.ntl, gc.ny, gc.nx, phic, phif,
+    hipLaunchKernelGGL(k_prolong_phi, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.t0, tc0, gc.ny, gc.nx, phic, phif,
                        sc_in, sc_out);
     DS_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, double *betaf, double *neg, double sc_in0,
-                        double sc_in1, double sc_out, hipStream_t st) {
+                        double sc_in1, double sc_out, hipStream_t st, i64 tc0, i64 Nzc) {
+    if (gf.ncl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ncl);
-    hipLaunchKernelGGL(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.ncl, gc.ny, gc.nx, gc.Nz, gf.Nz,
-                       betac, betaf, neg, sc_in0, sc_in1, sc_out);
+    hipLaunchKernelGGL(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.t0, tc0, gc.ny, gc.nx,
+                       Nzc < 0 ? gc.Nz : Nzc, gf.Nz, betac, betaf, neg, sc_in0, sc_in1, sc_out);
     DS_HIP(hipGetLastError());
     return 0;
 }

@@ -131,7 +131,11 @@ static void cmd_create(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[
             const mxArray *a = mxGetField(S, 0, names[i]);
             if (a && !mxIsEmpty(a)) st[i] = sized(a, &L->p, fields[i], names[i]);
         }
-    L->ctx = dotsocp_create(&L->p, (int)opt(O, "device", 0), 1);
+    /* opts.ngpu: time slabs on that many devices of this process (at least two time nodes per slab) */
+    int ngpu = (int)opt(O, "ngpu", 1);
+    if (ngpu > L->p.nt / 2) ngpu = (int)(L->p.nt / 2);
+    L->ctx = (ngpu > 1) ? dotsocp_create_multi(&L->p, (int)opt(O, "device", 0), ngpu)
+                        : dotsocp_create(&L->p, (int)opt(O, "device", 0), 1);
     if (!L->ctx) mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());
     if (dotsocp_set_profiling(L->ctx, 1) != 0) fail(L);        /* var.time columns (solver_socp_inPALM.m:339-341) */
     if (dotsocp_upload(L->ctx, DOTSOCP_F_C, cvec) != 0) fail(L);

@@ -301,6 +301,9 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
         rho0s[lv] = rho0s[lv] / (rho0s[lv].sum() / N)
         rho1s[lv] = rho1s[lv] / (rho1s[lv].sum() / N)
     on_device = transfer == "device"
+    # opts.ngpu (extension, as in the MEX gateway): every level is cut into time slabs on that many devices of this one
+    # process (a level with few time nodes gets fewer slabs: at least two nodes per slab)
+    ngpu = int(_get(opts, "ngpu", 1) or 1)
     var, model = initialize(rho0s[0], rho1s[0], nts[0], lazy_zeros=on_device)
     if weighted:
         model.weight = ws[0]
@@ -310,7 +313,7 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
         for lv in range(L):
             InitialScaling(var, model, o["scaling"], last, dim=dim, weighted=weighted)
             ctx = InPALMContext(var, dict(o, tol=tols[lv]), model, weighted=weighted, device=device, method=method,
-                                warm_from=prev)
+                                warm_from=prev, ngpu=max(1, min(ngpu, nts[lv] // 2)))
             if prev is not None:
                 prev.close()
                 prev = None

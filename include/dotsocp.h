@@ -230,7 +230,10 @@ int dotsocp_recover_outputs(dotsocp_ctx *ctx, const double *rho0, const double *
  * interpolate.m:20-84, between the finished context `coarse` and the context `fine` of the next level (created
  * from the fine level's InitialScaling scalars, c and weight uploaded, begin() not yet called; grid
  * 2 (n - 1) + 1 per dimension).  Fills phi, q, alpha, z, beta of `fine` exactly as recoverOrgVar ->
- * jump_nextLevel -> InitialScaling -> upload would.  Same device, one-slab contexts. */
+ * jump_nextLevel -> InitialScaling -> upload would.  Either context may be cut into in-process time slabs
+ * (dotsocp_create / dotsocp_create_multi, any two slab counts and placements): a fine slab gathers the coarse
+ * layers it interpolates from out of the coarse slabs that own them (peer copies).  Contexts with an RCCL
+ * communicator attached are refused (DOTSOCP_EINVAL): their levels exchange state through the host. */
 int dotsocp_jump_next_level(dotsocp_ctx *coarse, dotsocp_ctx *fine);
 
 /* runHist.{kkt (len x 7, column-major), time, iter, pdGap} (:350-354); any pointer may be NULL */

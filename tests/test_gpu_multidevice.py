@@ -113,3 +113,34 @@ def test_free_running_multi_device_against_oracle():
     D.recoverOrgVar(var)
     errs = {f: _relerr(getattr(var, f), getattr(ovar, f)) for f in FIELDS}
     assert max(errs.values()) <= 1e-7, errs
+
+
+@pytest.mark.parametrize("case,ngpu", [("dot2d", 4), ("wdot2d", 3), ("dot1d", 4)])
+def test_multilevel_driver_on_time_slabs(case, ngpu):
+    """The whole multilevel driver (solver_dotsocp2d.m:154-250 and twins) with every level cut into time slabs of this one
+    process: dotsocp_jump_next_level between multi-slab contexts with DIFFERENT slab counts per level (a coarse level
+    with few time nodes gets fewer slabs), outputs recovered on the slabs.  Per-level iteration counts must equal the
+    one-slab run's, the outputs agree to the slab tolerance."""
+    if case == "dot1d":
+        rho0, rho1 = get_example_1d("gaussian", 129)
+        run = lambda o: D.solver_dotsocp1d(rho0, rho1, 33, 3, o, "inPALM")            # noqa: E731
+        opts = dict(tol=1e-4)
+    elif case == "wdot2d":
+        rho0, rho1 = get_example_2d("example1", 33, 33)
+        barrier = gene_barrier_of_circle_pillar()
+        weight = get_weight_by_barrier(33, 33, 17, barrier)
+        rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+        run = lambda o: D.solver_wdotsocp2d(rho0, rho1, 17, 2, dict(o, weight=weight), "inPALM", barrier=barrier)   # noqa: E731
+        opts = dict(tol=1e-3, maxit=400)
+    else:
+        rho0, rho1 = get_example_2d("example1", 33, 33)
+        run = lambda o: D.solver_dotsocp2d(rho0, rho1, 17, 3, o, "inPALM")            # noqa: E731
+        opts = dict(tol=1e-4)
+    ref_out, ref_time, ref_ml, _ = run(dict(opts))
+    got_out, got_time, got_ml, _ = run(dict(opts, ngpu=ngpu))
+    assert [int(t["Iters"]) for t in got_time[:-1]] == [int(t["Iters"]) for t in ref_time[:-1]]
+    np.testing.assert_array_equal(got_ml["iter"], ref_ml["iter"])
+    np.testing.assert_allclose(got_ml["kkt"], ref_ml["kkt"], rtol=1e-5, atol=1e-9)
+    for k in ref_out:
+        err = np.max(np.abs(got_out[k] - ref_out[k])) / max(np.max(np.abs(ref_out[k])), 1e-300)
+        assert err <= 1e-7, (k, err)
