@@ -366,6 +366,7 @@ struct QRhsArgs {
     const double *q_anchor, *alpha_anchor;
     double c1, c2, om_rho, rho;
     APend ap;          // pending scaling of alpha_in (VAR 0)
+    int xcd;           // XCD-aware tile order
     // KKT variant (VAR 0, single slab): per-workgroup partial sums, r = A' alpha^+ - c per node, DOT complementarity scalars
     double *partials, *resid;
     double kappa, dsD;
@@ -407,10 +408,14 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
     };
     double a0prev = 0.0, rhoTprev = 0.0;
     const int lane = threadIdx.x, xl = threadIdx.y;
-    const i64 y = (i64)blockIdx.x * TILE_Y + lane;
-    const i64 x = (i64)blockIdx.y * TILE_X + xl;
+    // XCD-aware tile order (device_utils.h): tiles that are neighbours in y or x run on the same XCD back to back, so
+    // what they share -- the cache lines of the by rows (length ny - 1: never line-aligned), the phi row above, the
+    // neighbour tile's edge that is recomputed here -- is served by that XCD's L2 instead of a second HBM fetch
+    const BlockId blk = block_id(a.xcd != 0);
+    const i64 y = (i64)blk.x * TILE_Y + lane;
+    const i64 x = (i64)blk.y * TILE_X + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
-    const i64 t0 = ((i64)blockIdx.z * a.zstride + a.z0) * a.TC;
+    const i64 t0 = ((i64)blk.z * a.zstride + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ntl) ? t0 + a.TC : g.ntl;
     auto put = [&](i64 k, double qn, double an, double ain) {
         a.q_out[k] = qn;
@@ -670,7 +675,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
 #pragma unroll
                     for (int wv = 1; wv < TILE_X; ++wv) v += red[wv][i];
                 }
-            const i64 b = blockIdx.x + (i64)gridDim.x * (blockIdx.y + (i64)gridDim.y * blockIdx.z);
+            const i64 b = blk.x + (i64)gridDim.x * (blk.y + (i64)gridDim.y * blk.z);
             a.partials[b * S_COUNT + lane] = v;
         }
     }
@@ -763,6 +768,8 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     a.TC = TC;
     a.z0 = z0;
     a.zstride = zstride;
+    static const int xcd = getenv("DOTSOCP_QXCD") ? atoi(getenv("DOTSOCP_QXCD")) : 1;
+    a.xcd = xcd;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(TILE_Y, TILE_X);
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
