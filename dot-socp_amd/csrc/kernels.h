@@ -210,9 +210,12 @@ struct KktHalo {
 };
 i64 kkt_partials_needed(const Grid &g);
 // parts: bit mask of 1 node, 2 cell (+ q0 entries; needs a stored z), 4 bx edges, 8 by edges
+// layer0: only the slab's first node / edge layer (the folded path on time slabs leaves it to this launch; parts 1|4|8),
+// partial sums in their own regions; resid (part 1): A' alpha - c per visited node
 int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double *phi, const double *q,
                const double *alpha, const double *z, const double *beta, const double *cvec,
-               const double *weight, const KktHalo &halo, const KktWork &w, int parts, hipStream_t st);
+               const double *weight, const KktHalo &halo, const KktWork &w, int parts, hipStream_t st,
+               bool layer0 = false, double *resid = nullptr);
 // fused path: pending multiplier step (beta_in -> beta_out, distinct buffers) + the cell part of the sums
 // edges (one slab, after a q-step in its KKT variant): also the F*B*beta' sums of every edge and the momentum terms of
 // the edges on tile borders (a.q2 / a.sx / a.sy are scratch; q_new = q^{k+1})

@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
                                                          const double *__restrict__ beta,
                                                          const double *__restrict__ cvec,
                                                          const double *__restrict__ weight,
-                                                         KktHalo halo, double *__restrict__ partials) {
+                                                         KktHalo halo, double *__restrict__ partials,
+                                                         double *__restrict__ resid) {
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const bool inb = (y < g.ny) && (x < g.nx);
@@ -82,6 +83,10 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
                 if (y <= g.ny - 2) r += (-c.ay) * alpha[byo + y + (g.ny - 1) * x];
                 const double cv = cvec[node], pv = phi[node];
                 r = r - cv;
+                // A' alpha - c of the node for launch_rhs_sigma_fix.  The right-hand side it corrects is the q-step's, which
+                // on a slab's first layer still lacks the left neighbour's cell (k_rhs_fixup adds it later, from the
+                // scaled alpha): the same term is left out here
+                if (resid) resid[node] = (tl == 0 && !g.first) ? r - c.at * halo.a0_prev[y + g.ny * x] : r;
                 S[S_DUAL1] += r * r;
                 S[S_CPHI] += cv * pv;
                 S[S_PHI2] += pv * pv;
@@ -338,15 +343,20 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_kkt_cells(Grid g, LoopC
                 };
                 xch[par][xl][lane] = make_double2(b[1], p3);
                 __syncthreads();
+                // edge layers this launch sums over: the slab's own ones, except the first of a slab that is not the
+                // first (the left neighbour's tail is missing here: k_kkt's one-layer launch takes that layer)
+                const bool sumLayer = (tl < g.ntl) && !(tl == 0 && !g.first);
                 if (own) {
                     if (x < g.nx - 1) {
                         const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
                         if (xl < TILE_X - 1) {
+                            if (sumLayer) {
                             const double2 r = xch[par][xl + 1][lane];
                             double acc = r.x + b[2];
                             acc += r.y;
                             acc += p4;
                             dual(e, acc);
+                            }
                         } else {
                             a.q2[e] = b[2] + p4;             // partial; the right tile's part arrives in sx
                         }
@@ -358,10 +368,12 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_kkt_cells(Grid g, LoopC
                     if (y < g.ny - 1) {
                         const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
                         if (lane < 63) {
-                            double acc = u5 + b[6];
-                            acc += u7;
-                            acc += p8;
-                            dual(e, acc);
+                            if (sumLayer) {
+                                double acc = u5 + b[6];
+                                acc += u7;
+                                acc += p8;
+                                dual(e, acc);
+                            }
                         } else {
                             a.q2[e] = b[6] + p8;             // partial; the upper tile's part arrives in sy
                         }
@@ -414,6 +426,7 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
     const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 tbeg = (i64)blockIdx.z * BND_TC, tend = (tbeg + BND_TC < g.ntl) ? tbeg + BND_TC : g.ntl;
     for (i64 tl = tbeg; tl < tend; ++tl) {
+    if (tl == 0 && !g.first) continue;            // time slabs: that layer belongs to k_kkt's one-layer launch
     if (DIR == 0) {
         const i64 y = u, x = (i64)blockIdx.y * TILE_X + (TILE_X - 1);
         if (y < g.ny && x < g.nx - 1) {
@@ -522,27 +535,33 @@ static i64 kkt_region_blocks(const Grid &g) {
     return m;
 }
 
-// four regions (node, cell, bx, by launches) of per-workgroup partial sums; a region is as long as
-// the largest grid that writes to it, entries no launch writes stay zero (buffer cleared once)
-i64 kkt_partials_needed(const Grid &g) { return 4 * kkt_region_blocks(g); }
+// KKT_REGIONS regions of per-workgroup partial sums: 0-3 node / cell / bx / by launches (folded path: q-step / cells / the two
+// border launches), 4-6 the one-layer launches of the folded path on time slabs; a region is as long as the largest grid
+// that writes to it, entries no launch writes stay zero (buffer cleared before every use)
+#define KKT_REGIONS 7
+i64 kkt_partials_needed(const Grid &g) { return KKT_REGIONS * kkt_region_blocks(g); }
 
 // parts: bit mask of 1 node, 2 cell (+ q0 entries, needs a stored z), 4 bx edges, 8 by edges
 int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double *phi, const double *q,
                const double *alpha, const double *z, const double *beta, const double *cvec, const double *weight,
-               const KktHalo &halo, const KktWork &w, int parts, hipStream_t st) {
+               const KktHalo &halo, const KktWork &w, int parts, hipStream_t st, bool layer0, double *resid) {
     dim3 grid;
     i64 chunk;
     kkt_geometry(g, grid, chunk);
     const i64 region = kkt_region_blocks(g);
-    if (4 * region > w.maxBlocks) {
+    if (KKT_REGIONS * region > w.maxBlocks) {
         set_error("kkt workspace too small");
         return DOTSOCP_EINVAL;
     }
+    // layer0 (folded path on a time slab): the first node / edge layer only, partial sums in regions 4-6
+    const int base = layer0 ? 4 : 0;
+    if (layer0) { chunk = 1; grid.z = 1; }
     const dim3 blk(TILE_Y, TILE_X);
 #define KKT_PART(W, P, slot)                                                                                     \
     if (parts & P)                                                                                               \
     hipLaunchKernelGGL((k_kkt<W, P>), grid, blk, 0, st, g, c, k, chunk, phi, q, alpha, z, beta, cvec, weight, halo, \
-                       w.partials + (slot) * region * S_COUNT)
+                       w.partials + ((layer0 && (slot) > 0 ? (slot) - 1 : (slot)) + base) * region * S_COUNT,    \
+                       (P == 1) ? resid : nullptr)
     if (weight) { KKT_PART(true, 1, 0); KKT_PART(true, 2, 1); KKT_PART(true, 4, 2); KKT_PART(true, 8, 3); }
     else { KKT_PART(false, 1, 0); KKT_PART(false, 2, 1); KKT_PART(false, 4, 2); KKT_PART(false, 8, 3); }
 #undef KKT_PART
@@ -598,8 +617,8 @@ double *kkt_qstep_partials(const Grid &g, const KktWork &w) {
 
 int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st) {
     // w.sums: [S_COUNT] result followed by [KKT_SLICES][S_COUNT] intermediate sums
-    hipLaunchKernelGGL(k_kkt_final, dim3(S_COUNT, KKT_SLICES), dim3(256), 0, st, w.partials, 4 * kkt_region_blocks(g),
-                       w.sums + S_COUNT);
+    hipLaunchKernelGGL(k_kkt_final, dim3(S_COUNT, KKT_SLICES), dim3(256), 0, st, w.partials,
+                       KKT_REGIONS * kkt_region_blocks(g), w.sums + S_COUNT);
     hipLaunchKernelGGL(k_kkt_final2, dim3(1), dim3(64), 0, st, w.sums + S_COUNT, KKT_SLICES, w.sums);
     DS_HIP(hipGetLastError());
     return 0;

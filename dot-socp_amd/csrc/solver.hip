@@ -873,7 +873,12 @@ int Solver::flush_alpha() {
 int Solver::sigma_scale_folded(double factor) {
     DS_CHECK(flush_alpha());
     DS_CHECK(push_beta_op(1.0, factor));
-    apend = true; amul = 1.0; adiv = factor;
+    if (multi()) {
+        // time slabs: the u0 tail for the right neighbour is formed from alpha in memory before the next q-step runs
+        FOR_SLABS(s) DS_CHECK(launch_scale(s.alpha, s.g.NqAlloc, 1.0, factor, s.st));
+    } else {
+        apend = true; amul = 1.0; adiv = factor;
+    }
     u0_fresh = false;
     FOR_SLABS(s) DS_CHECK(launch_rhs_sigma_fix(s.w0, s.w1, s.c, s.g.Nphi, factor, s.st));
     return 0;
@@ -1114,10 +1119,6 @@ KktCoef Solver::kkt_coef() const {
 // kkt: the iteration ends with a KKT check and the q-step runs in its KKT variant (one slab: part == 0)
 int Solver::phase_q(int part, bool kkt) {
     if (!(fused && qrhs)) DS_CHECK(flush_alpha());
-    if (kkt) {
-        // all four regions of partial sums are cleared here; kkt_sums() then only adds the cell and border launches
-        FOR_SLABS(s) DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
-    }
     if (part != 1) prof_begin(PH_QSTEP);
     FOR_SLABS(s) {
         hipStream_t st = (part == 1) ? s.st_z : s.st;
@@ -1277,6 +1278,11 @@ int Solver::kkt_sums(double *S, bool folded) {
     FOR_SLABS(s) {
         KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
         if (rest) DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, s.st));
+        // folded path on a slab that is not the first: its first node / edge layer, now that the left neighbour's last
+        // cell has arrived (the q-step, the cell pass and the border launches skipped that layer)
+        if (folded && !s.g.first)
+            DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, 1 | 4 | 8, s.st, true,
+                                s.w1));
         DS_CHECK(launch_kkt_final(s.g, s.kw, s.st));
         if (remote()) break;
         DS_HIP(hipMemcpyAsync(s.h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s.st));
@@ -1471,8 +1477,8 @@ int Solver::step(bool *brk) {
     const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                  // :220
     // known before the q-step (the time limit is the one trigger that is not: such a check takes the unfolded path)
     const bool kkt_due = opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit;
-    // one slab, fused dataflow: the q-step of a checking iteration accumulates its share of the KKT sums itself
-    const bool fold = kkt_due && kkt_fold && fused && qrhs && !multi();
+    // fused dataflow: the q-step of a checking iteration accumulates its share of the KKT sums itself
+    const bool fold = kkt_due && kkt_fold && fused && qrhs;
     bool split = overlap && fused && halo_pending;
     for (auto &s : slabs) split = split && s.fg.chunks >= 2;
     if (split) {
@@ -1504,15 +1510,20 @@ int Solver::step(bool *brk) {
     }
     bool split_q = overlap && fused && qrhs && multi() && cone_split_enabled();
     for (auto &s : slabs) split_q = split_q && qstep_rhs_chunks(s.g, s.fg) >= 3;
+    if (fold) {
+        // every region of partial sums is cleared before the q-step writes region 0; kkt_sums() then only adds the cell,
+        // border and (time slabs) first-layer launches
+        FOR_SLABS(s) DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+    }
     if (split_q) {
         // the chunks of the q-step that need neither neighbour run on stream_z while the phi head and the adjoint
         // tails travel on the main stream; the first and the last chunk follow the exchange
         FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_fork, s.st));    // phi^{k+1} and the cone pass are complete
         DS_CHECK(phase_z_tails());                               // enqueued first: the exchange gets its CUs at once
         FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
-        DS_CHECK(phase_q(1));
+        DS_CHECK(phase_q(1, fold));
         FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
-        DS_CHECK(phase_q(2));
+        DS_CHECK(phase_q(2, fold));
     } else {
         DS_CHECK(phase_z_tails());
         DS_CHECK(phase_q(0, fold));

@@ -466,6 +466,10 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
         const double di = tbnd ? c.dinv2 : c.dinv1;
         const bool hasCell = inb && (tl < g.ncl);
         const bool tails = (tl == 0) && !g.first;                // slab mode: the left neighbour's share of the first layer
+        // KKT variant on a slab that is not the first: the sums of its first node / edge layer need the left neighbour's
+        // last cell (alpha0 for A' alpha, the density for the momentum terms) -- they are left to a one-layer launch of
+        // k_kkt after the exchange; the q0 entries of that layer need no neighbour and stay here
+        const bool lay0 = KKT && tails;
         // ---------------- loads ----------------
         const i64 eX = hasBx ? g.offBx + g.bxLayer * tl + yc + g.ny * xc : node;
         const i64 eY = hasBy ? g.offBy + g.byLayer * tl + yc + (g.ny - 1) * xc : node;
@@ -535,11 +539,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
             tmp += c.ax * pXl;
             ainX = q_calc<WEIGHTED, MULT>(c, tmp, gX, dc, di, wX, alX, a.ap, qXn, aXn, ubx);
             if (KKT) {
-                entry(tmp, qXn, aXn, wX);
                 abx = aXn;
                 qbx = qXn;
-                mbx = a.kappa * (wX * aXn);
-                S[Q_M2] += mbx * mbx;
+                if (!lay0) {
+                    entry(tmp, qXn, aXn, wX);
+                    mbx = a.kappa * (wX * aXn);
+                    S[Q_M2] += mbx * mbx;
+                }
             }
         }
         if (hasBy) {
@@ -547,11 +553,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
             tmp += c.ay * pYl;
             ainY = q_calc<WEIGHTED, MULT>(c, tmp, gY, dc, di, wY, alY, a.ap, qYn, aYn, uby);
             if (KKT) {
-                entry(tmp, qYn, aYn, wY);
                 aby = aYn;
                 qby = qYn;
-                mby = a.kappa * (wY * aYn);
-                S[Q_M2] += mby * mby;
+                if (!lay0) {
+                    entry(tmp, qYn, aYn, wY);
+                    mby = a.kappa * (wY * aYn);
+                    S[Q_M2] += mby * mby;
+                }
             }
         }
         double ubx_l = 0.0, abx_l = 0.0, uby_b = 0.0, aby_b = 0.0;
@@ -616,7 +624,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
             if (y >= 1) r += c.ay * uby_m;
             if (y <= g.ny - 2) r += (-c.ay) * uby;
             a.rhs[node] = r + cv;
-            if (KKT) {
+            if (KKT && !lay0) {
                 double ra = 0.0;                       // A' alpha^+ in the order of k_kkt's node part
                 if (tl >= 1) ra += c.at * a0prev;
                 if (tl < g.ncl) ra += (-c.at) * a0;
@@ -675,7 +683,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopC
 #pragma unroll
                     for (int wv = 1; wv < TILE_X; ++wv) v += red[wv][i];
                 }
-            const i64 b = blk.x + (i64)gridDim.x * (blk.y + (i64)gridDim.y * blk.z);
+            // one row per tile and CHUNK (a slab's q-step runs as several launches over disjoint sets of chunks)
+            const i64 b = blk.x + (i64)gridDim.x * (blk.y + (i64)gridDim.y * ((i64)blk.z * a.zstride + a.z0));
             a.partials[b * S_COUNT + lane] = v;
         }
     }
