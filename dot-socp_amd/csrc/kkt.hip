@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
 // tile the two sums are taken on the spot (one load of alpha), for an edge on the tile's right / upper border the raw
 // partial sums go to q2 / sx / sy exactly as in the cone pass and k_kkt_bnd completes them.  The q0 entries' share of
 // ||q||^2, ||alpha||^2, ... is left to the q-step in this mode.
-template <bool WEIGHTED, bool EDGES, int OCC = 1>
-__global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
+template <bool WEIGHTED, bool EDGES>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
                                                                const double *__restrict__ phi,
                                                                const double *__restrict__ alpha,
                                                                const double *__restrict__ weight,
@@ -587,14 +587,8 @@ int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, 
         DS_HIP(hipGetLastError());
         return 0;
     }
-    static const int occ = getenv("DOTSOCP_KKT_OCC") ? atoi(getenv("DOTSOCP_KKT_OCC")) : 0;
-    if (occ) {
-        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true, 3>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-        else hipLaunchKernelGGL((k_kkt_cells<false, true, 3>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-    } else {
-        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-        else hipLaunchKernelGGL((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-    }
+    if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    else hipLaunchKernelGGL((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
     DS_HIP(hipGetLastError());
     for (int dir = 0; dir < 2; ++dir) {
         const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;

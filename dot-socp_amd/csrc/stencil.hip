@@ -385,8 +385,8 @@ struct QRhsArgs {
 // sigma update the right-hand side of the next phi-step is rhs + r - r / factor (launch_rhs_sigma_fix) instead of a new pass.
 enum { Q_Q2 = 0, Q_ALPHA2, Q_APHI2, Q_PRIM1, Q_QALPHA, Q_CPHI, Q_PHI2, Q_DUAL1, Q_MRHOB, Q_M2, Q_RHOB2, Q_COUNT };
 
-template <bool WEIGHTED, int VAR, bool KKT = false, int OCC = 1>
-__global__ void __launch_bounds__(TILE_Y *TILE_X, OCC) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
+template <bool WEIGHTED, int VAR, bool KKT = false>
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
     __shared__ double xch[2][TILE_X][TILE_Y];
     __shared__ double xcha[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // alpha^+ of the bx edge
     __shared__ double xchr[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // density at the node
@@ -783,14 +783,8 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     dim3 blk(TILE_Y, TILE_X);
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
     if (var == 0 && a.partials) {          // iteration with a KKT check
-        static const int occ = getenv("DOTSOCP_KKT_OCC") ? atoi(getenv("DOTSOCP_KKT_OCC")) : 0;
-        if (occ) {
-            if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true, 4>), grid, blk, 0, st, g, c, fg, a);
-            else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true, 4>), grid, blk, 0, st, g, c, fg, a);
-        } else {
-            if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
-            else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
-        }
+        if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
+        else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
     } else if (a.weight) {
         if (var == 0) QRHS_LAUNCH(true, 0); else if (var == 1) QRHS_LAUNCH(true, 1); else QRHS_LAUNCH(true, 2);
     } else {
