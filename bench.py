@@ -269,7 +269,8 @@ def main():
 
     done = ctx.run(args.warmup)
     assert done == args.warmup
-    D.capi.check(D.capi.lib().dotsocp_set_profiling(ctx._ctx, 1))
+    if not os.environ.get("DOTSOCP_BENCH_NOPROF"):
+        D.capi.check(D.capi.lib().dotsocp_set_profiling(ctx._ctx, 1))
     fence()
     t0 = time.perf_counter()
     done = ctx.run(args.steps)
