@@ -87,6 +87,9 @@ struct TriReduced {
     i64 slab_n[DS_MAX_WORLD]; // time nodes of every slab
 };
 
+// PMAX: compile-time bound on the number of slabs -- the four sweep arrays are then fully unrolled and live in registers
+// (a run-time bound of DS_MAX_WORLD puts 2 KB per thread into scratch: the generic instance, used above 16 slabs only)
+template <int PMAX>
 __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, const double *__restrict__ recv,
                                                       double *__restrict__ back, double *__restrict__ zero_work) {
     const i64 i = (i64)blockIdx.x * 128 + threadIdx.x;
@@ -121,8 +124,10 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
         return;
     }
     const double ap = tri_aprime(g, m);
-    double A[DS_MAX_WORLD], B[DS_MAX_WORLD], al[DS_MAX_WORLD], ga[DS_MAX_WORLD];
-    for (int p = 0; p < q.P; ++p) {
+    double A[PMAX], B[PMAX], al[PMAX], ga[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        if (p >= q.P) break;
         const i64 n = q.slab_n[p];
         const bool first = (p == 0), last = (p == q.P - 1);
         // first / last entries of A_p^{-1} e_first (vf, vl) and A_p^{-1} e_last (wf, wl)
@@ -158,7 +163,9 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
     }
     // back substitution; slab p needs L_{p-1} and F_{p+1}
     double Fnext = 0.0;                            // F_{p+1}
-    for (int p = q.P - 1; p >= 0; --p) {
+#pragma unroll
+    for (int p = PMAX - 1; p >= 0; --p) {
+        if (p >= q.P) continue;
         const double F = A[p] + B[p] * Fnext;
         const double Lprev = (p > 0) ? al[p - 1] + ga[p - 1] * F : 0.0;
         back[p * stride + i] = Lprev;
@@ -337,7 +344,11 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
     TriReduced q{};
     q.P = pc.world; q.rank = rank; q.l0 = l0; q.nl = nl; q.nt = nt;
     for (int p = 0; p < pc.world; ++p) q.slab_n[p] = slab_n[p];
-    hipLaunchKernelGGL(k_tri_reduced, dim3((unsigned)((nl + 127) / 128)), dim3(128), 0, st, t, q, recv, back, zero_work);
+    const dim3 grid((unsigned)((nl + 127) / 128));
+    if (pc.world <= 4) hipLaunchKernelGGL(k_tri_reduced<4>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    else if (pc.world <= 8) hipLaunchKernelGGL(k_tri_reduced<8>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    else if (pc.world <= 16) hipLaunchKernelGGL(k_tri_reduced<16>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    else hipLaunchKernelGGL(k_tri_reduced<DS_MAX_WORLD>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
     DS_HIP(hipGetLastError());
     return 0;
 }
