@@ -120,9 +120,7 @@ struct Solver {
     int xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, double *dst, size_t dpitch, size_t width,
                 size_t height);
     int sync_all();                    // host waits for every stream of every slab
-    // fork / join of the second stream of every slab
-    int fork_z(bool also_halo_event = false);
-    int join_z();
+    int fork_z();                      // every slab's second stream starts behind what its main stream holds so far
     bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process
     int world = 1;                  // total number of slabs

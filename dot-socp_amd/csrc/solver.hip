@@ -103,20 +103,10 @@ int Solver::xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, doub
 }
 
 // second streams: fork behind everything enqueued on the slab's main stream ...
-int Solver::fork_z(bool also_halo_event) {
-    (void)also_halo_event;
+int Solver::fork_z() {
     FOR_SLABS(s) {
         DS_HIP(hipEventRecord(s.ev_fork, s.st));
         DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
-    }
-    return 0;
-}
-
-// ... and make the main stream wait for what the second one has been given since
-int Solver::join_z() {
-    FOR_SLABS(s) {
-        DS_HIP(hipEventRecord(s.ev_join, s.st_z));
-        DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
     }
     return 0;
 }

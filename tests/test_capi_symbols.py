@@ -98,3 +98,23 @@ def test_mex_gateways_build_and_reject_bad_calls_without_a_gpu():
             prhs, plhs = (vp * 3)(*hs), (vp * 1)()
             assert L.fmx_call(ctypes.cast(fn, vp), 0, plhs, 3, prhs) == 1
             assert L.fmx_error_id() == b"mexBFd:invalidNumInputs"
+
+
+def test_field_len_is_pure_host_arithmetic():
+    """dotsocp_field_len (what the MEX gateways check their arrays against) needs no device."""
+    from dotsocp_amd import capi
+    L = capi.lib()
+    p = capi.Problem()
+    p.dim, p.weighted, p.ny, p.nx, p.nt = 2, 0, 5, 6, 4
+    Nphi, Nz = 5 * 6 * 4, 5 * 6 * 3
+    Nq = Nz + 5 * 5 * 4 + 4 * 6 * 4
+    want = {capi.F_PHI: Nphi, capi.F_C: Nphi, capi.F_Q: Nq, capi.F_ALPHA: Nq, capi.F_WEIGHT: Nq, capi.F_Z: 10 * Nz,
+            capi.F_BETA: 10 * Nz}
+    for f, n in want.items():
+        assert L.dotsocp_field_len(p, f) == n
+    assert L.dotsocp_field_len(p, 99) == -1
+    p.dim, p.ny, p.nx, p.nt = 1, 0, 9, 5                      # 1-D: grid nx x nt, cone Nz x 6
+    assert L.dotsocp_field_len(p, capi.F_Q) == 9 * 4 + 8 * 5 and L.dotsocp_field_len(p, capi.F_BETA) == 6 * 9 * 4
+    p.nt = 1
+    assert L.dotsocp_field_len(p, capi.F_PHI) == -1
+    assert L.dotsocp_canary_check() == 0                      # nothing guarded, nothing damaged
