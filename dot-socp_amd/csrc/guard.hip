@@ -49,6 +49,7 @@ int guarded_malloc(void **p, size_t bytes) {
     DS_HIP(hipMalloc((void **)&base, padded + 2 * GUARD));
     // the slack between the payload's end and the rear band is pattern too: an overrun by one element is seen
     const size_t head = GUARD / 8, tail = (padded - bytes + GUARD) / 8;
+    (void)hipGetLastError();       // a stale error of an earlier, failed call must not be blamed on the fill launches
     hipLaunchKernelGGL(k_fill_pattern, dim3(4), dim3(256), 0, nullptr, (unsigned long long *)base, head);
     // payload sizes are multiples of 8 (doubles, double2); the tail starts right behind the payload
     hipLaunchKernelGGL(k_fill_pattern, dim3(4), dim3(256), 0, nullptr, (unsigned long long *)(base + GUARD + bytes / 8 * 8),
