@@ -222,6 +222,10 @@ int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double 
 int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, FusedArgs a,
                             const double *phi, const double *alpha, const double *weight, const KktWork &w,
                             hipStream_t st, bool edges = false, const double *q_new = nullptr);
+// the rescale block's five norms of an iterate whose multiplier step is pending (a.q_old, a.q, a.beta_in [+ pending ops]):
+// S_PHI2, S_Q2, S_ALPHA2, S_Z2, S_BETA2 as partial sums (clear w.partials first, launch_kkt_final afterwards)
+int launch_norms(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, FusedArgs a, const double *phi,
+                 const double *alpha, const double *weight, const KktWork &w, hipStream_t st);
 // partial sums of the q-step's KKT variant: region 0 of w.partials
 double *kkt_qstep_partials(const Grid &g, const KktWork &w);
 int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st);

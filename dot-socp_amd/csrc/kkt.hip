@@ -207,7 +207,10 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
 // tile the two sums are taken on the spot (one load of alpha), for an edge on the tile's right / upper border the raw
 // partial sums go to q2 / sx / sy exactly as in the cone pass and k_kkt_bnd completes them.  The q0 entries' share of
 // ||q||^2, ||alpha||^2, ... is left to the q-step in this mode.
-template <bool WEIGHTED, bool EDGES>
+//
+// NORMS = true: only ||z||^2 and ||beta'||^2 of the iterate whose multiplier step is still pending, nothing stored (the
+// rescale block's every-100-iterations check, solver_socp_inPALM.m:139-149, when no KKT check precedes it).
+template <bool WEIGHTED, bool EDGES, bool NORMS = false>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
                                                                const double *__restrict__ phi,
                                                                const double *__restrict__ alpha,
@@ -272,7 +275,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 }
                 cur = nxt;
                 curo = nxto;
-                if (own) {
+                if (own && NORMS) {
+                    S[S_Z2] += zs;
+                    S[S_BETA2] += bs;
+                }
+                if (own && !NORMS) {
 #pragma unroll
                     for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
                     // ||z - Pi_Q(z - sigma beta')||^2 (:240-241) with proj_row's arithmetic, the projected row never
@@ -401,6 +408,19 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
         const i64 bb = blockIdx.x + (i64)gridDim.x * (blockIdx.y + (i64)gridDim.y * blockIdx.z);
         partials[bb * S_COUNT + lane] = v;
     }
+}
+
+// sum of squares of n doubles, one partial row (slot `slot` of S_COUNT) per workgroup
+__global__ void __launch_bounds__(256) k_sumsq(const double *__restrict__ x, i64 n, int slot, double *__restrict__ partials) {
+    double v = 0.0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) v += x[i] * x[i];
+    __shared__ double red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < S_COUNT)
+        partials[(i64)blockIdx.x * S_COUNT + threadIdx.x] = ((int)threadIdx.x == slot) ? ((red[0] + red[1]) + red[2]) + red[3] : 0.0;
 }
 
 // The edges on tile borders (one slab).  DIR 0: bx edges (y, x+1/2, t) with x % TILE_X == TILE_X - 1 -- their right density
@@ -536,9 +556,9 @@ static i64 kkt_region_blocks(const Grid &g) {
 }
 
 // KKT_REGIONS regions of per-workgroup partial sums: 0-3 node / cell / bx / by launches (folded path: q-step / cells / the two
-// border launches), 4-6 the one-layer launches of the folded path on time slabs; a region is as long as the largest grid
+// border launches), 4-6 the one-layer launches of the folded path on time slabs (launch_norms: one region per launch); a region is as long as the largest grid
 // that writes to it, entries no launch writes stay zero (buffer cleared before every use)
-#define KKT_REGIONS 7
+#define KKT_REGIONS 8
 i64 kkt_partials_needed(const Grid &g) { return KKT_REGIONS * kkt_region_blocks(g); }
 
 // parts: bit mask of 1 node, 2 cell (+ q0 entries, needs a stored z), 4 bx edges, 8 by edges
@@ -601,6 +621,35 @@ int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, 
 #undef BND
         DS_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+// ||phi||^2, ||q||^2, ||alpha||^2 (owned entries), ||z||^2, ||beta||^2 of the iterate with its multiplier step pending:
+// the five norms of the rescale block without materialising anything (regions 0-4 of the partial sums)
+int launch_norms(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, FusedArgs a, const double *phi,
+                 const double *alpha, const double *weight, const KktWork &w, hipStream_t st) {
+    const i64 region = kkt_region_blocks(g);
+    a.TC = fg.TC;
+    if (g.Nz > 0) {
+        dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
+        double *part = w.partials + 1 * region * S_COUNT;
+        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, false, true>), grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
+        else hipLaunchKernelGGL((k_kkt_cells<false, false, true>), grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
+    }
+    // q-layout arrays: q0 cells, then the owned bx and by layers (a slab's halo layers are not its own)
+    struct R { const double *x; i64 n; int slot, reg; };
+    const R rs[] = {{phi, g.Nphi, S_PHI2, 0},
+                    {a.q, g.Nz, S_Q2, 2}, {a.q + g.offBx, g.bxLayer * g.ntl, S_Q2, 3}, {a.q + g.offBy, g.byLayer * g.ntl, S_Q2, 4},
+                    {alpha, g.Nz, S_ALPHA2, 5}, {alpha + g.offBx, g.bxLayer * g.ntl, S_ALPHA2, 6},
+                    {alpha + g.offBy, g.byLayer * g.ntl, S_ALPHA2, 7}};
+    for (const R &r : rs) {
+        if (r.n <= 0) continue;
+        i64 blocks = (r.n + 256 * 64 - 1) / (256 * 64);
+        if (blocks > region) blocks = region;
+        double *part = w.partials + r.reg * region * S_COUNT;
+        hipLaunchKernelGGL(k_sumsq, dim3((unsigned)blocks), dim3(256), 0, st, r.x, r.n, r.slot, part);
+    }
+    DS_HIP(hipGetLastError());
     return 0;
 }
 

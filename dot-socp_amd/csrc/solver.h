@@ -213,6 +213,8 @@ struct Solver {
     int phase_mult();
     int materialise();
     int kkt_sums(double *S, bool folded = false);
+    int reduce_sums(double *S);
+    int norms_light(double *S);
     int kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk, bool folded = false);
     int scale_state(double a_mul, double a_div, double q_div, bool with_c);
     void update_coef();

@@ -1264,7 +1264,6 @@ int Solver::kkt_sums(double *S, bool folded) {
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.btail_by; }, slabs[0].g.byLayer));
         DS_CHECK(group_end());
     }
-    for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
     FOR_SLABS(s) {
         KktHalo halo{s.a0_prev, s.a0w_prev, s.btail_bx, s.btail_by};
         if (rest) DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, rest, s.st));
@@ -1273,6 +1272,15 @@ int Solver::kkt_sums(double *S, bool folded) {
         if (folded && !s.g.first)
             DS_CHECK(launch_kkt(s.g, lc, k, s.phi, s.q, s.alpha, s.z, s.beta, s.c, s.weight, halo, s.kw, 1 | 4 | 8, s.st, true,
                                 s.w1));
+    }
+    return reduce_sums(S);
+}
+
+// The partial sums every slab holds -> S[0 .. S_COUNT) summed over the slabs (host, in slab order) resp. over the ranks
+// (all-reduce); S[S_COUNT] = the wall clock (one slab per process: the maximum over the ranks)
+int Solver::reduce_sums(double *S) {
+    for (int i = 0; i <= S_COUNT; ++i) S[i] = 0.0;
+    FOR_SLABS(s) {
         DS_CHECK(launch_kkt_final(s.g, s.kw, s.st));
         if (remote()) break;
         DS_HIP(hipMemcpyAsync(s.h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s.st));
@@ -1300,6 +1308,24 @@ int Solver::kkt_sums(double *S, bool folded) {
     return 0;
 }
 
+// The five norms of solver_socp_inPALM.m:140-141 for an iterate whose multiplier step is still pending (the state between
+// two iterations of the fused loop): one pass over beta that stores nothing, three sums of squares.  S as from kkt_sums().
+int Solver::norms_light(double *S) {
+    DS_CHECK(ensure_halo());
+    DS_CHECK(flush_alpha());
+    const KktCoef k = kkt_coef();
+    FOR_SLABS(s) {
+        DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+        FusedArgs a{};
+        a.q_old = s.q_old;
+        a.q = s.q;
+        a.beta_in = s.beta;
+        set_pending(a);
+        DS_CHECK(launch_norms(s.g, lc, k, s.fg, a, s.phi, s.alpha, s.weight, s.kw, s.st));
+    }
+    return reduce_sums(S);
+}
+
 // solver_socp_inPALM.m:138-190
 int Solver::rescale_block() {
     bool scaleYes = false;
@@ -1313,6 +1339,8 @@ int Solver::rescale_block() {
             // sigma by it, so sigma * ||alpha|| is what it was with the sigma of the check -- no pass over the state.
             for (int i = 0; i < S_COUNT; ++i) S[i] = last_S[i];
             sig = last_S_sigma;
+        } else if (method == DOTSOCP_METHOD_INPALM && fused && deferred && norm_cache) {
+            DS_CHECK(norms_light(S));          // nothing is materialised, the multiplier step stays pending
         } else {
             DS_CHECK(materialise());
             DS_CHECK(ensure_z());

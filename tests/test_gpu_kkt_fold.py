@@ -82,3 +82,32 @@ def test_folded_free_running_stops_like_unfolded(monkeypatch):
     got, h1, s1 = _run(rho0, rho1, 16, dict(tol=1e-4))
     assert h1["iter"][-1] == h0["iter"][-1] and h1["len"] == h0["len"]
     np.testing.assert_allclose(h1["kkt"], h0["kkt"], rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("ny,nx,nt,K", [(32, 32, 16, 230), (33, 17, 9, 130)])
+def test_rescale_checks_every_100_iterations(ny, nx, nt, K, monkeypatch):
+    """Past the second rescale the loop checks the norm ratio every 100 iterations (solver_socp_inPALM.m:139-149).  No KKT
+    check precedes those iterations, so the five norms come from the light pass (cell kernel in norms-only mode + three
+    sums of squares, nothing materialised) -- against the oracle, and against the path that materialises z and runs
+    the full KKT sums (DOTSOCP_NORM_CACHE=0)."""
+    from oracle.inpalm import InPALMState
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    opts = dict(tol=0.0, maxit=K)
+    ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, "inPALM", None)
+    st = InPALMState(ovar, oo, omodel)
+    st.run()
+    o_hist, o_sigma = st.finish()
+    monkeypatch.setenv("DOTSOCP_NORM_CACHE", "1")
+    got, h1, s1 = _run(rho0, rho1, nt, opts)
+    np.testing.assert_array_equal(h1["iter"], o_hist["iter"])
+    assert abs(s1 - o_sigma) <= 1e-12 * abs(o_sigma)
+    assert abs(got.cScale - ovar.cScale) <= 1e-12 * ovar.cScale and abs(got.dScale - ovar.dScale) <= 1e-12 * ovar.dScale
+    for f in FIELDS:
+        a, b = getattr(got, f), getattr(ovar, f)
+        assert np.max(np.abs(a - b)) / np.max(np.abs(b)) <= 1e-9, f
+    monkeypatch.setenv("DOTSOCP_NORM_CACHE", "0")
+    ref, h0, s0 = _run(rho0, rho1, nt, opts)
+    assert abs(s1 - s0) <= 1e-13 * abs(s0)
+    for f in FIELDS:
+        a, b = getattr(got, f), getattr(ref, f)
+        assert np.max(np.abs(a - b)) / np.max(np.abs(b)) <= 1e-11, f
