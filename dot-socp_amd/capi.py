@@ -90,10 +90,37 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torchs_hip_runtime():
+    """The PyTorch-ROCm wheel ships its own copy of the HIP runtime (same SONAME as the system one), and whichever copy
+    a process loads first serves everything loaded later.  If libdotsocp came first, with the system runtime, a later
+    `import torch` would bring a second runtime and find "no ROCm-capable device".  So when torch is installed but not
+    yet imported, its copy is loaded here first: libdotsocp then binds to it (same SONAME) and a later `import torch`
+    finds its own runtime already in place -- the import order no longer matters.  DOTSOCP_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("DOTSOCP_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    for name in ("libamdhip64.so", "libamdhip64.so.7"):
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     """Load libdotsocp.so (built by `make -C dot-socp_amd/csrc` / __graft_entry__.build())."""
     global _lib
     if _lib is None:
+        _share_torchs_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first "

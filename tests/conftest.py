@@ -3,9 +3,9 @@ import sys
 
 import pytest
 
-# torch ships its own copy of the HIP runtime; whichever copy is loaded first serves the whole process.  The
-# full-size tests keep their data in torch tensors next to libdotsocp calls, so torch has to come first (as in
-# bench.py): loaded after libdotsocp it finds "no ROCm-capable device".
+# torch ships its own copy of the HIP runtime; whichever copy is loaded first serves the whole process.  The binding takes
+# care of the order by itself (capi._share_torchs_hip_runtime, tests/test_gpu_import_order.py); importing torch here first
+# merely keeps the suite on the path most of it was written on.
 try:
     import torch  # noqa: F401
 except Exception:       # noqa: BLE001
