@@ -1362,6 +1362,10 @@ int Solver::rescale_block() {
     const bool second = (rescale == 2) && (maxFeas < 5e-3) && (it >= 50) && (relGap < 1e-2);
     if (!(first || second || scaleYes)) return 0;
     if (!scaleYes) DS_CHECK(norms(normPhis, normAlps));
+    // A multiplier step that is still pending belongs to the OLD scaling (z^k = Pi(BF q^{k-1} + d - beta^{k-1}) with the old
+    // d and the unscaled q, beta): it is executed before anything is rescaled.  (Right after a KKT check nothing is
+    // pending; the every-100-iterations check took its norms without touching the state.)
+    DS_CHECK(materialise());
     const double dScale2 = normPhis, cScale2 = normAlps;
     sigma = sigma * (cScale2 / dScale2);
     norm_c = norm_c / cScale2;

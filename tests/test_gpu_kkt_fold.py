@@ -84,18 +84,21 @@ def test_folded_free_running_stops_like_unfolded(monkeypatch):
     np.testing.assert_allclose(h1["kkt"], h0["kkt"], rtol=1e-6, atol=1e-10)
 
 
-@pytest.mark.parametrize("ny,nx,nt,K", [(32, 32, 16, 230), (33, 17, 9, 130)])
-def test_rescale_checks_every_100_iterations(ny, nx, nt, K, monkeypatch):
+@pytest.mark.parametrize("ny,nx,nt,K,sigma0", [(32, 32, 16, 230, 1.0), (33, 17, 9, 130, 1.0), (16, 16, 8, 320, 0.01)])
+def test_rescale_checks_every_100_iterations(ny, nx, nt, K, sigma0, monkeypatch):
     """Past the second rescale the loop checks the norm ratio every 100 iterations (solver_socp_inPALM.m:139-149).  No KKT
     check precedes those iterations, so the five norms come from the light pass (cell kernel in norms-only mode + three
     sums of squares, nothing materialised) -- against the oracle, and against the path that materialises z and runs
-    the full KKT sums (DOTSOCP_NORM_CACHE=0)."""
+    the full KKT sums (DOTSOCP_NORM_CACHE=0).  On the small grids (the coarse levels of a multilevel run) the check does
+    fire a rescale: the pending multiplier step then has to be executed under the OLD scaling first.  The sigma0 = 0.01
+    case is one where a check past iteration 100 does rescale (the oracle ends with rescale = 4)."""
     from oracle.inpalm import InPALMState
     rho0, rho1 = get_example_2d("example1", ny, nx)
-    opts = dict(tol=0.0, maxit=K)
+    opts = dict(tol=0.0, maxit=K, sigma=sigma0)
     ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, "inPALM", None)
     st = InPALMState(ovar, oo, omodel)
     st.run()
+    assert st.rescale == (4 if sigma0 != 1.0 else 3)
     o_hist, o_sigma = st.finish()
     monkeypatch.setenv("DOTSOCP_NORM_CACHE", "1")
     got, h1, s1 = _run(rho0, rho1, nt, opts)
