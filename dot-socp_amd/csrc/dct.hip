@@ -1150,6 +1150,17 @@ static void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DCT_LDS_MAX);
 }
 
+// Function attributes belong to the (function, device) pair: a process that drives several GPUs (dotsocp_create_multi)
+// has to raise the dynamic-LDS limit once on EVERY device it launches on.  true = not done yet on the current device.
+static bool first_on_this_device(unsigned long long &done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const unsigned long long bit = 1ull << dev;
+    if (done_mask & bit) return false;
+    done_mask |= bit;
+    return true;
+}
+
 bool dct_plan_is_pow2(const DctPlan *p) { return p->log2n > 0; }
 
 static bool dct_wg_enabled() {
@@ -1173,11 +1184,10 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     if (dct_wg_enabled() && vec && mode != 2 && ((i64)n << lp) >= 2 * DCT_WG_THREADS) {
-        static bool once_wg = false;
-        if (!once_wg) {
+        static unsigned long long done_wg = 0;
+        if (first_on_this_device(done_wg)) {
             allow_big_lds(k_dct_strided_wg<0, 512>); allow_big_lds(k_dct_strided_wg<1, 512>);
             allow_big_lds(k_dct_strided_wg<0, 1024>); allow_big_lds(k_dct_strided_wg<1, 1024>);
-            once_wg = true;
         }
         // long lines: one workgroup of 1024 threads with the whole LDS (twice the rows) keeps 16 waves per CU
         // like two workgroups of 512 would, and widens the contiguous segment per line to 128 bytes
@@ -1206,8 +1216,8 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     }
 #define LAUNCH_STRIDED(M, V)                                                                                   \
     do {                                                                                                       \
-        static bool once = false;                                                                              \
-        if (!once) { allow_big_lds(k_dct_strided<M, V>); once = true; }                                        \
+        static unsigned long long done = 0;                                                                    \
+        if (first_on_this_device(done)) allow_big_lds(k_dct_strided<M, V>);                                    \
         hipLaunchKernelGGL((k_dct_strided<M, V>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, lg, \
                            lp, sa, p->tw, p->ww);                                                              \
     } while (0)
@@ -1272,11 +1282,10 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         }
         const i64 linesPerBlock = (i64)(2 * DCT_WAVES) << lrw;
         const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
-        static bool once = false;
-        if (!once) {
+        static unsigned long long done = 0;
+        if (first_on_this_device(done)) {
             allow_big_lds(k_dct_axis0<false>); allow_big_lds(k_dct_axis0<true>);
             allow_big_lds(k_dct_axis0_wg<false>); allow_big_lds(k_dct_axis0_wg<true>);
-            once = true;
         }
         if (dct_wg_enabled() && ((n / 2) << lp) >= 2 * DCT_WG_THREADS) {
             // same rows per workgroup (4 << lrw complex rows), twice the threads, shared by all of them
