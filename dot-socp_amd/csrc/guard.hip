@@ -31,7 +31,32 @@ __global__ void k_fill_pattern(unsigned long long *p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = PATTERN;
 }
 
+// one workgroup that idles for about `ticks` of the 100 MHz wall clock (bounded: every wave leaves after 2^20 polls at most)
+__global__ void k_stall(long long ticks) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 20); ++i) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 }  // namespace
+
+// Race detector for the multi-stream paths (DOTSOCP_STRESS_STREAMS=1): a short stall of pseudo-random length (0 .. 300 us)
+// in front of whatever is enqueued next on `st`.  Every ordering between streams has to come from an event then, not from
+// kernels happening to take as long as they usually do; results must not change (tests/test_gpu_multidevice.py).
+bool stream_stress_enabled() {
+    static const bool on = getenv("DOTSOCP_STRESS_STREAMS") && atoi(getenv("DOTSOCP_STRESS_STREAMS")) != 0;
+    return on;
+}
+
+void stream_stress(hipStream_t st) {
+    static unsigned long long state = 0x9e3779b97f4a7c15ull;
+    state ^= state << 13; state ^= state >> 7; state ^= state << 17;       // xorshift: reproducible sequence per process
+    if ((state & 3) == 0) return;                                          // a quarter of the calls add nothing
+    const long long ticks = (long long)((state >> 8) % 30000);             // up to 300 us at 100 MHz
+    hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, st, ticks);
+}
 
 bool canary_enabled() {
     const char *e = getenv("DOTSOCP_CANARY");

@@ -19,6 +19,9 @@ void guarded_free(void *p);
 // description of the first few.  Synchronises the current device.
 int canary_check(std::string *report);
 bool canary_enabled();
+// DOTSOCP_STRESS_STREAMS=1: random stalls in front of the work of every slab stream (guard.hip)
+bool stream_stress_enabled();
+void stream_stress(hipStream_t st);
 
 template <class T>
 inline int dmalloc(T **p, i64 n) {

@@ -38,7 +38,14 @@ int Solver::use_dev(int d) {
     return 0;
 }
 
-int Solver::use(const Slab &s) { return use_dev(s.dev); }
+int Solver::use(const Slab &s) {
+    DS_CHECK(use_dev(s.dev));
+    if (stream_stress_enabled() && begun && !finished) {       // race detector: perturb the relative timing of the streams
+        if (s.st) stream_stress(s.st);
+        if (s.st_z) stream_stress(s.st_z);
+    }
+    return 0;
+}
 
 int Solver::sync_all() {
     for (auto &s : slabs) {

@@ -144,3 +144,46 @@ def test_multilevel_driver_on_time_slabs(case, ngpu):
     for k in ref_out:
         err = np.max(np.abs(got_out[k] - ref_out[k])) / max(np.max(np.abs(ref_out[k])), 1e-300)
         assert err <= 1e-7, (k, err)
+
+
+_STRESS_SCRIPT = """
+import hashlib, sys
+import numpy as np
+import dotsocp_amd as D
+from oracle import driver as OD
+from oracle.examples import get_example_2d
+h = hashlib.sha256()
+for method, ngpu, ny, nx, nt, K in (("inPALM", 4, 40, 36, 64, 24), ("inPALM", 3, 33, 17, 48, 20), ("PALM", 3, 24, 40, 48, 14),
+                                    ("acc-ADMM", 2, 32, 24, 16, 14)):
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    var, model = D.initialize(rho0, rho1, nt)
+    o = OD.default_opts(dict(tol=0.0, maxit=K), method, False)
+    D.InitialScaling(var, model, True, None, dim=2)
+    ctx = D.InPALMContext(var, o, model, method=method, ngpu=ngpu)
+    ctx.run(-1)
+    hist, sigma = ctx.finish(download=True)
+    out = ctx.outputs()
+    ctx.close()
+    for a in (var.phi, var.q, var.z, var.alpha, var.beta, hist["kkt"], out["rho"]):
+        assert np.all(np.isfinite(a))
+        h.update(np.ascontiguousarray(a).tobytes())
+print("HASH", h.hexdigest())
+"""
+
+
+def test_random_stream_stalls_change_nothing():
+    """Race detector (DOTSOCP_STRESS_STREAMS=1, csrc/guard.hip): stalls of random length in front of the work of every
+    slab stream -- main and second stream of every slab -- so that no ordering between streams can come from kernels
+    happening to take their usual time.  All three loops on 2 - 4 concurrent slabs must produce bit-identical iterates,
+    KKT histories and outputs with and without the stalls."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for stress in ("0", "1", "1"):
+        env = dict(os.environ, DOTSOCP_STRESS_STREAMS=stress, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        out = subprocess.run([sys.executable, "-c", _STRESS_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+        hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][-1])
+    assert hashes[0] == hashes[1] == hashes[2], hashes
