@@ -60,6 +60,15 @@ def test_one_process_per_slab_matches_single_process(world, tsolve, NT, monkeypa
     _one_process_per_slab(world, tsolve, NT, "inPALM", monkeypatch)
 
 
+@pytest.mark.parametrize("world,tsolve,NT", [(4, "tridiag", 64), (2, "dct", 32)])
+def test_one_process_per_slab_under_random_stream_stalls(world, tsolve, NT, monkeypatch):
+    """The rank processes run with DOTSOCP_STRESS_STREAMS=1 (random stalls in front of the work of both streams of every
+    rank, csrc/guard.hip): the overlap of the cone chunks / middle q-step chunks with the neighbour exchanges must rest
+    on events alone."""
+    monkeypatch.setenv("DOTSOCP_STRESS_STREAMS", "1")
+    _one_process_per_slab(world, tsolve, NT, "inPALM", monkeypatch)
+
+
 @pytest.mark.parametrize("world,NT", [(2, 16), (3, 48)])
 def test_palm_one_process_per_slab(world, NT, monkeypatch):
     """solver_socp_PALM.m's loop in time-slab mode, one process per slab"""
