@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_tri_final_reg(TriGeom g, const double *
 static int tri_reg_width(i64 ntl) {
     static const bool on = !(getenv("DOTSOCP_TRI_REG") && atoi(getenv("DOTSOCP_TRI_REG")) == 0);
     if (!on) return 0;
-    return ntl <= 16 ? 16 : (ntl <= 32 ? 32 : 0);
+    return ntl <= 16 ? 16 : (ntl <= 32 ? 32 : (ntl <= 64 ? 64 : 0));
 }
 
 static TriGeom make_geom(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc) {
@@ -331,6 +331,7 @@ int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, con
     const int rw = tri_reg_width(g.ntl);
     if (rw == 16) hipLaunchKernelGGL(k_tri_local_reg<16>, grid, dim3(256), 0, st, t, r, send);
     else if (rw == 32) hipLaunchKernelGGL(k_tri_local_reg<32>, grid, dim3(256), 0, st, t, r, send);
+    else if (rw == 64) hipLaunchKernelGGL(k_tri_local_reg<64>, grid, dim3(256), 0, st, t, r, send);
     else hipLaunchKernelGGL(k_tri_local, grid, dim3(256), 0, st, t, r, send);
     DS_HIP(hipGetLastError());
     return 0;
@@ -360,6 +361,7 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
     const int rw = tri_reg_width(g.ntl);
     if (rw == 16) hipLaunchKernelGGL(k_tri_final_reg<16>, grid, dim3(256), 0, st, t, back, x);
     else if (rw == 32) hipLaunchKernelGGL(k_tri_final_reg<32>, grid, dim3(256), 0, st, t, back, x);
+    else if (rw == 64) hipLaunchKernelGGL(k_tri_final_reg<64>, grid, dim3(256), 0, st, t, back, x);
     else hipLaunchKernelGGL(k_tri_final, grid, dim3(256), 0, st, t, back, x, qinv);
     DS_HIP(hipGetLastError());
     return 0;

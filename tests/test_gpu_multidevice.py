@@ -39,7 +39,9 @@ def _run(rho0, rho1, nt, opts, method, weight=None, outputs=False, **kw):
 @pytest.mark.parametrize("method,ngpu,ny,nx,nt,K", [
     ("inPALM", 2, 32, 24, 16, 30), ("inPALM", 3, 40, 36, 48, 30), ("inPALM", 4, 64, 64, 64, 25),
     ("inPALM", 8, 32, 32, 128, 20), ("ALG2", 2, 33, 17, 9, 20), ("PALM", 2, 32, 24, 16, 25), ("PALM", 3, 24, 40, 48, 20),
-    ("acc-ADMM", 2, 32, 24, 16, 25), ("acc-ADMM", 4, 32, 32, 64, 20)])
+    ("acc-ADMM", 2, 32, 24, 16, 25), ("acc-ADMM", 4, 32, 32, 64, 20),
+    # slabs of 33 .. 64 time nodes (register-resident tridiagonal kernels of width 64) and longer ones (memory-resident)
+    ("inPALM", 2, 24, 20, 100, 20), ("PALM", 2, 24, 20, 70, 14), ("inPALM", 2, 16, 12, 150, 12)])
 def test_multi_device_matches_single_slab(method, ngpu, ny, nx, nt, K):
     rho0, rho1 = get_example_2d("example1", ny, nx)
     opts = dict(tol=0.0, maxit=K)
