@@ -385,11 +385,15 @@ struct QRhsArgs {
 // sigma update the right-hand side of the next phi-step is rhs + r - r / factor (launch_rhs_sigma_fix) instead of a new pass.
 enum { Q_Q2 = 0, Q_ALPHA2, Q_APHI2, Q_PRIM1, Q_QALPHA, Q_CPHI, Q_PHI2, Q_DUAL1, Q_MRHOB, Q_M2, Q_RHOB2, Q_COUNT };
 
-template <bool WEIGHTED, int VAR, bool KKT = false>
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
-    __shared__ double xch[2][TILE_X][TILE_Y];
-    __shared__ double xcha[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // alpha^+ of the bx edge
-    __shared__ double xchr[KKT ? 2 : 1][KKT ? TILE_X : 1][KKT ? TILE_Y : 1];   // density at the node
+template <bool WEIGHTED, int VAR, bool KKT = false, int QTX = TILE_X>
+__global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 1)) k_qstep_rhs(Grid g, LoopCoef c, FusedGeom fg, QRhsArgs a) {
+    __shared__ double xch[2][QTX][TILE_Y];
+    // phi of the layer the march stands on, with a one-entry halo in x and y: every phi entry is fetched ONCE per tile and
+    // layer (own column as the "t + 1" value of the step before, the four halo strips by the border lanes) and the x / y
+    // neighbours are read from here -- read from global they cost a second fetch of the whole layer, a step later
+    __shared__ double ph[2][QTX + 2][TILE_Y + 2];
+    __shared__ double xcha[KKT ? 2 : 1][KKT ? QTX : 1][KKT ? TILE_Y : 1];   // alpha^+ of the bx edge
+    __shared__ double xchr[KKT ? 2 : 1][KKT ? QTX : 1][KKT ? TILE_Y : 1];   // density at the node
     double S[Q_COUNT];     // KKT only (dead code otherwise)
     if (KKT) {
 #pragma unroll
@@ -413,7 +417,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     // neighbour tile's edge that is recomputed here -- is served by that XCD's L2 instead of a second HBM fetch
     const BlockId blk = block_id(a.xcd != 0);
     const i64 y = (i64)blk.x * TILE_Y + lane;
-    const i64 x = (i64)blk.y * TILE_X + xl;
+    const i64 x = (i64)blk.y * QTX + xl;
     const bool inb = (y < g.ny) && (x < g.nx);
     const i64 t0 = ((i64)blk.z * a.zstride + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ntl) ? t0 + a.TC : g.ntl;
@@ -433,9 +437,22 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     };
     double u0prev = 0.0;
     double p0 = 0.0;
+    const bool hasBx0 = inb && (x < g.nx - 1), hasBy0 = inb && (y < g.ny - 1);
+    const bool rightCol = hasBx0 && (xl == QTX - 1), topRow = hasBy0 && (lane == TILE_Y - 1);
     if (inb) {
         const i64 node0 = y + g.ny * (x + g.nx * t0);
         p0 = a.phi[node0];
+        // halo strips of the chunk's first layer
+        double hx = 0.0, hl = 0.0, hy = 0.0, hb = 0.0;
+        if (rightCol) hx = a.phi[node0 + g.ny];
+        if (xl == 0 && x >= 1) hl = a.phi[node0 - g.ny];
+        if (topRow) hy = a.phi[node0 + 1];
+        if (lane == 0 && y >= 1) hb = a.phi[node0 - 1];
+        ph[0][xl + 1][lane + 1] = p0;
+        if (xl == QTX - 1) ph[0][QTX + 1][lane + 1] = hx;
+        if (xl == 0) ph[0][0][lane + 1] = hl;
+        if (lane == TILE_Y - 1) ph[0][xl + 1][TILE_Y + 1] = hy;
+        if (lane == 0) ph[0][xl + 1][0] = hb;
         if (t0 > 0) {       // cell in front of the chunk (owned by the previous chunk): recompute, do not store
             const i64 k = node0 - g.plane;
             double tmp = (-c.at) * a.phi[k];
@@ -459,6 +476,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     const bool belowTile = inb && (lane == 0) && (y >= 1);       // the by edge below belongs to the tile there
     const bool sxOwn = hasBx && ((x % fg.XB) == fg.XB - 1), syOwn = hasBy && ((y & 63) == 63);
     int par = 0;
+    __syncthreads();                                              // ph[0] is complete
     for (i64 tl = t0; tl < t1; ++tl) {
         const i64 node = yc + g.ny * (xc + g.nx * tl);
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
@@ -474,9 +492,15 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
         const i64 eX = hasBx ? g.offBx + g.bxLayer * tl + yc + g.ny * xc : node;
         const i64 eY = hasBy ? g.offBy + g.byLayer * tl + yc + (g.ny - 1) * xc : node;
         const i64 k0 = hasCell ? node : 0;                       // q0 entries exist for tl < ncl only
-        const double pTl = a.phi[hasCell ? node + g.plane : node];
-        const double pXl = a.phi[hasBx ? node + g.ny : node];
-        const double pYl = a.phi[hasBy ? node + 1 : node];
+        const i64 nodeT = hasCell ? node + g.plane : node;       // the layer of the next step (this one again at the end)
+        const double pTl = a.phi[nodeT];
+        double hx = 0.0, hl = 0.0, hy = 0.0, hb = 0.0;           // its halo strips
+        if (rightCol) hx = a.phi[nodeT + g.ny];
+        if (leftTile) hl = a.phi[nodeT - g.ny];
+        if (topRow) hy = a.phi[nodeT + 1];
+        if (belowTile) hb = a.phi[nodeT - 1];
+        const double pXl = ph[par][xl + 2][lane + 1];
+        const double pYl = ph[par][xl + 1][lane + 2];
         const double al0 = a.alpha_in[k0], alX = a.alpha_in[eX], alY = a.alpha_in[eY];
         const double g0 = a.q2v[k0];
         double gX = a.q2v[eX], gY = a.q2v[eY];
@@ -495,7 +519,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
         i64 eL = 0;
         if (leftTile) {
             eL = g.offBx + g.bxLayer * tl + y + g.ny * (x - 1);
-            pLl = a.phi[node - g.ny];
+            pLl = ph[par][0][lane + 1];
             alL = a.alpha_in[eL];
             gL = a.q2v[eL];
             if (WEIGHTED) wL = a.weight[eL];
@@ -506,7 +530,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
         i64 eB = 0;
         if (belowTile) {
             eB = g.offBy + g.byLayer * tl + (y - 1) + (g.ny - 1) * x;
-            pBl = a.phi[node - 1];
+            pBl = ph[par][xl + 1][0];
             alB = a.alpha_in[eB];
             gB = a.q2v[eB];
             if (WEIGHTED) wB = a.weight[eB];
@@ -593,6 +617,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
         // density at the node: mean of the two cells that meet there in time, zero outside (movmean's padding)
         const double rhoN = (rhoTprev + rhoT) / 2.0;
         xch[par][xl][lane] = ubx;
+        ph[par ^ 1][xl + 1][lane + 1] = pTl;
+        if (xl == QTX - 1) ph[par ^ 1][QTX + 1][lane + 1] = hx;
+        if (xl == 0) ph[par ^ 1][0][lane + 1] = hl;
+        if (lane == TILE_Y - 1) ph[par ^ 1][xl + 1][TILE_Y + 1] = hy;
+        if (lane == 0) ph[par ^ 1][xl + 1][0] = hb;
         if (KKT) {
             xcha[par][xl][lane] = abx;
             xchr[par][xl][lane] = rhoN;
@@ -638,7 +667,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 S[Q_CPHI] += cv * p0;
                 S[Q_PHI2] += p0 * p0;
                 // compute_kkt_dot_complement.m:10-18: momentum against mean density times b, edges inside the tile
-                if (x < g.nx - 1 && xl < TILE_X - 1) {
+                if (x < g.nx - 1 && xl < QTX - 1) {
                     const double rm = (rhoN + xchr[par][xl + 1][lane]) / 2.0;
                     const double rb = a.dsD * (rm * qbx);
                     const double d = mbx - rb;
@@ -664,7 +693,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
     }
     if (KKT) {
         // workgroup reduction as in k_kkt: wavefront shuffles, LDS across the four wavefronts, one partial row per workgroup
-        __shared__ double red[TILE_X][Q_COUNT];
+        __shared__ double red[QTX][Q_COUNT];
         static const int slot[Q_COUNT] = {S_Q2, S_ALPHA2, S_APHI2, S_PRIM1, S_QALPHA, S_CPHI, S_PHI2, S_DUAL1, S_MRHOB, S_M2, S_RHOB2};
 #pragma unroll
         for (int i = 0; i < Q_COUNT; ++i) {
@@ -681,7 +710,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_rhs(Grid g, LoopCoef c
                 if (slot[i] == lane) {
                     v = red[0][i];
 #pragma unroll
-                    for (int wv = 1; wv < TILE_X; ++wv) v += red[wv][i];
+                    for (int wv = 1; wv < QTX; ++wv) v += red[wv][i];
                 }
             // one row per tile and CHUNK (a slab's q-step runs as several launches over disjoint sets of chunks)
             const i64 b = blk.x + (i64)gridDim.x * (blk.y + (i64)gridDim.y * ((i64)blk.z * a.zstride + a.z0));
@@ -781,6 +810,21 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     a.xcd = xcd;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(TILE_Y, TILE_X);
+    // the plain inPALM instance may run on tiles twice as wide (the recomputed x - 1 edge and the phi halo columns cost
+    // half as much); the KKT variant keeps the tile of k_kkt_bnd, which finishes the edges on ITS tile borders
+    // (1024 x 1024 x 128: 18.35 -> 17.6 GB per launch by the PMC counters, same time; small grids keep the narrow tile:
+    // they need the workgroup count more than the bytes)
+    const char *qe = getenv("DOTSOCP_QTX");                   // read per launch: the tests switch it inside one process
+    const int qtx_env = qe ? atoi(qe) : 0;
+    const int qtx = qtx_env ? qtx_env : ((fg.nyblk * fg.nxblk * zcount >= 8192 && !a.weight) ? 2 * TILE_X : TILE_X);
+    if (var == 0 && !a.partials && qtx == 2 * TILE_X) {
+        dim3 grid2((unsigned)fg.nyblk, (unsigned)((g.nx + 2 * TILE_X - 1) / (2 * TILE_X)), (unsigned)zcount);
+        dim3 blk2(TILE_Y, 2 * TILE_X);
+        if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, false, 2 * TILE_X>), grid2, blk2, 0, st, g, c, fg, a);
+        else hipLaunchKernelGGL((k_qstep_rhs<false, 0, false, 2 * TILE_X>), grid2, blk2, 0, st, g, c, fg, a);
+        DS_HIP(hipGetLastError());
+        return 0;
+    }
 #define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
     if (var == 0 && a.partials) {          // iteration with a KKT check
         if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);

@@ -114,3 +114,19 @@ def test_rescale_checks_every_100_iterations(ny, nx, nt, K, sigma0, monkeypatch)
     for f in FIELDS:
         a, b = getattr(got, f), getattr(ref, f)
         assert np.max(np.abs(a - b)) / np.max(np.abs(b)) <= 1e-11, f
+
+
+@pytest.mark.parametrize("ny,nx,nt,K", [(100, 70, 20, 30), (65, 129, 33, 25), (63, 5, 7, 20), (64, 8, 9, 12), (130, 9, 5, 15),
+                                         (256, 256, 64, 30)])
+def test_wide_qstep_tile_changes_nothing(ny, nx, nt, K, monkeypatch):
+    """The plain inPALM q-step runs on 64 x 8 tiles on large grids and on 64 x 4 tiles otherwise (DOTSOCP_QTX forces
+    either): every entry goes through the same arithmetic in both, so the trajectories must agree to the last bit."""
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    monkeypatch.setenv("DOTSOCP_QTX", "4")
+    ref, h0, s0 = _run(rho0, rho1, nt, dict(tol=0.0, maxit=K))
+    monkeypatch.setenv("DOTSOCP_QTX", "8")
+    got, h1, s1 = _run(rho0, rho1, nt, dict(tol=0.0, maxit=K))
+    assert s1 == s0
+    np.testing.assert_array_equal(h1["kkt"], h0["kkt"])
+    for f in FIELDS:
+        np.testing.assert_array_equal(getattr(got, f), getattr(ref, f))
