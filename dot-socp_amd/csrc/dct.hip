@@ -574,6 +574,11 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
 // staged row of the per-wave flavour above at the same LDS footprint -- the footprint, not registers,
 // caps the resident workgroups per CU, so this doubles the waves that overlap VALU, LDS and HBM phases.
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier that leaves the vector-memory counter alone: LDS hand-off only.  The pipelined kernels keep LDS-DMA
+// loads and global stores in flight across barriers (counted s_waitcnt vmcnt(N) of their own), which a fence would drain.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool RAWB = false>
 __device__ __forceinline__ void fft_rows_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T,
                                             const double2 *__restrict__ tw) {
     const int nst = (lg + 3) >> 2;
@@ -594,10 +599,11 @@ __device__ __forceinline__ void fft_rows_wg(double2 *rows, int lrows, int lg, in
             }
         }
         sl -= lr;
-        __syncthreads();
+        if (RAWB) lds_barrier(); else __syncthreads();
     }
 }
 
+template <bool RAWB = false>
 __device__ __forceinline__ void idct_combine_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T,
                                                 const double2 *__restrict__ ww) {
     const int n = 1 << lg, lh = lg - 1;
@@ -622,7 +628,7 @@ __device__ __forceinline__ void idct_combine_wg(double2 *rows, int lrows, int lg
         const double w0 = ww[0].x;
         r[0] = make_double2(w0 * r[0].x, w0 * r[0].y);
     }
-    __syncthreads();
+    if (RAWB) lds_barrier(); else __syncthreads();
 }
 
 #define DCT_WG_THREADS 512
@@ -684,6 +690,137 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
         }
         if (La < nLines) *(double2 *)(dst + La * n + 2 * j) = A;
         if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * n + 2 * j) = B;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined flavour (axis 0, n = 128 .. 1024).  What limits the kernels above is not a unit but the bytes in flight:
+// while a workgroup computes, its tile sits in LDS and nothing of it travels, and the LDS holds two tiles only (the
+// same kernels with the transform skipped run at the copy rate; the transform's time adds in full).  Here ONE
+// persistent workgroup of 512 threads per CU (two waves per SIMD, 256 registers each) walks tiles of 8192 doubles (whole lines, contiguous in memory) through
+// two LDS buffers, and the lines of a tile arrive by LDS-DMA (global_load_lds_dwordx4: no registers, so the loads of
+// tile k+1 and k+2 are in flight during the transform and the stores of tile k):
+//   wait for the DMA of tile k (counted: the stores of tile k-1 and the DMA of tile k+1 are younger and stay in
+//   flight) | raw lines -> paired rows in Makhoul / natural order, in place (all reads, barrier, all writes) |
+//   [inverse pre-processing] | FFT | post-processing + stores | DMA of tile k+2 into the buffer just drained.
+// The twiddle tables live in LDS too: an ordinary global load in the loop would make the compiler wait for
+// everything in flight.  LDS: 2 x 4 x (n + n/16) x 16 B + 1.5 n x 16 B = 160 KB at n = 1024.
+// ---------------------------------------------------------------------------------------------
+#define PIPE_THREADS 512
+#define PIPE_IT ((1 << (PIPE_LG_CPLX - 1)) / PIPE_THREADS)   // (row, j) items per thread
+#define PIPE_LG_CPLX 12   // complex elements per tile: 4096 = 8192 doubles = 64 KB of lines
+#define PIPE_NS 8         // global store instructions per wave and tile
+#define PIPE_ND 8         // LDS-DMA instructions per wave and tile (64 pieces of 1 KB over 8 waves)
+
+// one wave-instruction: 64 lanes x 16 B from each lane's global address to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform)
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// the register groups of fft_rows_wg for a length known at compile time (same plan, same arithmetic)
+template <int LG, int LROWS, int T, int ST = 0, int SL = LG>
+__device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, const double2 *__restrict__ tw) {
+    constexpr int NST = (LG + 3) >> 2;
+    constexpr int BASEB = LG / NST, EXTRA = LG % NST;
+    if constexpr (ST < NST) {
+        constexpr int LR = BASEB + (ST < EXTRA ? 1 : 0);
+        constexpr int LPR = LG - LR;
+        constexpr int TOTAL = 1 << (LROWS + LPR);
+        constexpr int RS = (1 << LG) + (1 << (LG - 4));
+#pragma unroll
+        for (int b = t; b < TOTAL; b += T) dif_group<LR>(rows + (b >> LPR) * RS, SL, b & ((1 << LPR) - 1), LG, tw);
+        lds_barrier();
+        fft_rows_pipe<LG, LROWS, T, ST + 1, SL - LR>(rows, t, tw);
+    }
+}
+
+template <bool INVERSE, int LG>
+__global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *__restrict__ src, double *__restrict__ dst,
+                                                                  int nTiles, const double2 *__restrict__ tw,
+                                                                  const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    constexpr int n = 1 << LG, lh = LG - 1;
+    constexpr int RS = n + (n >> 4);                  // complex elements per padded row
+    constexpr int lrows = PIPE_LG_CPLX - LG;          // 2^lrows rows (pairs of lines) per tile
+    constexpr int BUF = RS << lrows;                  // complex elements per buffer
+    double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (n >> 1); i += PIPE_THREADS) twS[i] = tw[i];
+    for (int i = tid; i < n; i += PIPE_THREADS) wwS[i] = ww[i];
+    const unsigned ldsBase = (unsigned)(uintptr_t)lds;
+    auto dma = [&](int tile, int b) {
+        const char *g = (const char *)(src + ((i64)tile << (PIPE_LG_CPLX + 1))) + (wave * PIPE_ND) * 1024 + lane * 16;
+        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16) + (unsigned)(wave * PIPE_ND) * 1024u;
+#pragma unroll
+        for (int i = 0; i < PIPE_ND; ++i) glds16(g + i * 1024, l0 + (unsigned)i * 1024u);
+    };
+    int tile = blockIdx.x;
+    const int stride = gridDim.x;
+    if (tile < nTiles) dma(tile, 0);
+    if (tile + stride < nTiles) dma(tile + stride, 1);
+    // items of the staging / store loops: (row, j < n / 2), four per thread
+    const int rr0 = tid >> lh, j0 = tid & ((1 << lh) - 1);
+    constexpr int DRR = PIPE_THREADS >> lh;          // row step of the second item
+    for (int it = 0; tile < nTiles; tile += stride, ++it) {
+        const int b = it & 1;
+        double2 *buf = lds + b * BUF;
+        // the DMA of this tile has landed when at most the younger operations are outstanding: the stores of the
+        // previous tile and the DMA of the next one (vector-memory operations of a wave complete in issue order)
+        if (tile + stride >= nTiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_ND) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_NS + PIPE_ND) : "memory");
+        lds_barrier();
+        // raw lines (n doubles apart, unpadded) -> rows of pairs: all reads, barrier, all writes (same buffer)
+        {
+            const double *raw = (const double *)buf;
+            double2 A[PIPE_IT], B[PIPE_IT];
+#pragma unroll
+            for (int u = 0; u < PIPE_IT; ++u) {
+                const int rr = rr0 + u * DRR;
+                A[u] = *(const double2 *)(raw + (2 * rr) * n + 2 * j0);
+                B[u] = *(const double2 *)(raw + (2 * rr + 1) * n + 2 * j0);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int u = 0; u < PIPE_IT; ++u) {
+                double2 *r = buf + (rr0 + u * DRR) * RS;
+                if (!INVERSE) {
+                    r[padi(j0)] = make_double2(A[u].x, B[u].x);
+                    r[padi(n - 1 - j0)] = make_double2(A[u].y, B[u].y);
+                } else {
+                    r[padi(2 * j0)] = make_double2(A[u].x, B[u].x);
+                    r[padi(2 * j0 + 1)] = make_double2(A[u].y, B[u].y);
+                }
+            }
+        }
+        lds_barrier();
+        if (INVERSE) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwS);
+        fft_rows_pipe<LG, lrows, PIPE_THREADS>(buf, tid, twS);
+        double *out = dst + ((i64)tile << (PIPE_LG_CPLX + 1));
+#pragma unroll
+        for (int u = 0; u < PIPE_IT; ++u) {
+            const int rr = rr0 + u * DRR;
+            const double2 *r = buf + rr * RS;
+            double2 Av, Bv;
+            if (!INVERSE) {
+                const double2 p0 = dct_post(r, 2 * j0, n, LG, wwS), p1 = dct_post(r, 2 * j0 + 1, n, LG, wwS);
+                Av = make_double2(p0.x, p1.x);
+                Bv = make_double2(p0.y, p1.y);
+            } else {
+                const double2 v0 = r[padi(bitrev(j0, LG))], v1 = r[padi(bitrev(n - 1 - j0, LG))];
+                Av = make_double2(v0.x, v1.x);
+                Bv = make_double2(v0.y, v1.y);
+            }
+            *(double2 *)(out + (2 * rr) * n + 2 * j0) = Av;
+            *(double2 *)(out + (2 * rr + 1) * n + 2 * j0) = Bv;
+        }
+        lds_barrier();                              // the buffer is drained
+        if (tile + 2 * stride < nTiles) dma(tile + 2 * stride, b);
     }
 }
 
@@ -1286,6 +1423,46 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         if (first_on_this_device(done)) {
             allow_big_lds(k_dct_axis0<false>); allow_big_lds(k_dct_axis0<true>);
             allow_big_lds(k_dct_axis0_wg<false>); allow_big_lds(k_dct_axis0_wg<true>);
+        }
+        // pipelined persistent kernel: whole tiles of 8192 doubles, enough of them to fill the chip twice
+        static const bool pipe = !(getenv("DOTSOCP_DCT_PIPE") && atoi(getenv("DOTSOCP_DCT_PIPE")) == 0);
+        const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
+        if (pipe && dct_wg_enabled() && lg >= 7 && lg <= 10 && map.nLines % tileLines == 0 &&
+            (((uintptr_t)src | (uintptr_t)dst) % 16 == 0)) {
+            static int cus[64] = {0};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                cus[dev] = v;
+            }
+            const i64 nTiles = map.nLines / tileLines;
+            const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+            if (nTiles >= 2 * (i64)ncu && nTiles < (1ll << 30)) {
+                static unsigned long long done_pipe = 0;
+                if (first_on_this_device(done_pipe)) {
+                    allow_big_lds(k_dct_axis0_pipe<false, 7>); allow_big_lds(k_dct_axis0_pipe<true, 7>);
+                    allow_big_lds(k_dct_axis0_pipe<false, 8>); allow_big_lds(k_dct_axis0_pipe<true, 8>);
+                    allow_big_lds(k_dct_axis0_pipe<false, 9>); allow_big_lds(k_dct_axis0_pipe<true, 9>);
+                    allow_big_lds(k_dct_axis0_pipe<false, 10>); allow_big_lds(k_dct_axis0_pipe<true, 10>);
+                }
+                const size_t rs = (size_t)n + (size_t)(n >> 4);
+                const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
+#define PIPE_LAUNCH(INV, LGV)                                                                                        \
+    hipLaunchKernelGGL((k_dct_axis0_pipe<INV, LGV>), dim3((unsigned)ncu), dim3(PIPE_THREADS), ldsPipe, st, src, dst, \
+                       (int)nTiles, p->tw, p->ww)
+                if (inverse) {
+                    if (lg == 10) PIPE_LAUNCH(true, 10); else if (lg == 9) PIPE_LAUNCH(true, 9);
+                    else if (lg == 8) PIPE_LAUNCH(true, 8); else PIPE_LAUNCH(true, 7);
+                } else {
+                    if (lg == 10) PIPE_LAUNCH(false, 10); else if (lg == 9) PIPE_LAUNCH(false, 9);
+                    else if (lg == 8) PIPE_LAUNCH(false, 8); else PIPE_LAUNCH(false, 7);
+                }
+#undef PIPE_LAUNCH
+                DS_HIP(hipGetLastError());
+                return 0;
+            }
         }
         if (dct_wg_enabled() && ((n / 2) << lp) >= 2 * DCT_WG_THREADS) {
             // same rows per workgroup (4 << lrw complex rows), twice the threads, shared by all of them

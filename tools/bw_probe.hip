@@ -129,6 +129,22 @@ __global__ void __launch_bounds__(64 * XB) aosoa8(const double *in, double *out,
     }
 }
 
+// soa8c with a plane stride that differs from the plane length (ps doubles between the planes of in / out, `skew` more
+// between in and out): do the ten streams of a wave collide on HBM channels when the planes are a multiple of 8 MiB apart?
+template <int XB>
+__global__ void __launch_bounds__(64 * XB) soa8s(const double *in, double *out, i64 ny, i64 nx, i64 nt, i64 tc, i64 ps) {
+    const i64 y = (i64)blockIdx.x * 64 + threadIdx.x, x = (i64)blockIdx.y * XB + threadIdx.y;
+    const i64 t0 = blockIdx.z * tc, t1 = (t0 + tc < nt) ? t0 + tc : nt;
+    for (i64 t = t0; t < t1; ++t) {
+        const i64 i = y + ny * (x + nx * t);
+        double v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = in[j * ps + i];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) out[j * ps + i] = v[j] * 1.0001;
+    }
+}
+
 template <class F>
 static double timeit(F f, int reps = 5) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -143,8 +159,9 @@ static double timeit(F f, int reps = 5) {
 int main() {
     const i64 ny = 1024, nx = 1024, nt = 127, Nz = ny * nx * nt, N = 10 * Nz;
     double *a, *b;
-    CK(hipMalloc(&a, N * 8)); CK(hipMalloc(&b, N * 8));
-    CK(hipMemset(a, 0, N * 8)); CK(hipMemset(b, 0, N * 8));
+    const i64 SLACK = 10 * (1 << 20);   // room for padded plane strides
+    CK(hipMalloc(&a, (N + SLACK) * 8)); CK(hipMalloc(&b, (N + SLACK) * 8));
+    CK(hipMemset(a, 0, (N + SLACK) * 8)); CK(hipMemset(b, 0, (N + SLACK) * 8));
     const double gb = 2.0 * N * 8 / 1e9;
     double ms;
     ms = timeit([&] { hipLaunchKernelGGL(copy8, dim3(16384), dim3(256), 0, 0, a, b, N); });
@@ -163,6 +180,14 @@ int main() {
     printf("soa8  64x4 tile, 8 chunks     : %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
     ms = timeit([&] { hipLaunchKernelGGL(soa8c<4>, dim3(ny / 64, nx / 4, 127), dim3(64, 4), 0, 0, a, b, ny, nx, nt, (i64)1); });
     printf("soa8  64x4 tile, 1 cell/thread: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+    for (i64 pad : {(i64)0, (i64)16, (i64)32, (i64)64, (i64)272, (i64)528, (i64)2064, (i64)4112, (i64)65552, (i64)(1 << 19) + 528}) {
+        ms = timeit([&] { hipLaunchKernelGGL(soa8s<4>, dim3(ny / 64, nx / 4, 8), dim3(64, 4), 0, 0, a, b, ny, nx, nt, (i64)16, Nz + pad); });
+        printf("soa8s 64x4 tile, 8 chunks, plane stride Nz + %7lld doubles: %.3f ms  %.0f GB/s\n", pad, ms, gb / ms * 1e3);
+    }
+    for (i64 skew : {(i64)16, (i64)528, (i64)4112}) {
+        ms = timeit([&] { hipLaunchKernelGGL(soa8s<4>, dim3(ny / 64, nx / 4, 8), dim3(64, 4), 0, 0, a, b + skew, ny, nx, nt, (i64)16, Nz); });
+        printf("soa8s 64x4 tile, 8 chunks, out shifted by %5lld doubles    : %.3f ms  %.0f GB/s\n", skew, ms, gb / ms * 1e3);
+    }
     ms = timeit([&] { hipLaunchKernelGGL(soa8p<4>, dim3(ny / 64, nx / 4), dim3(64, 4), 0, 0, a, b, ny, nx, nt); });
     printf("soa8p 64x4 tile, prefetch next: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
     ms = timeit([&] { hipLaunchKernelGGL(soa8y<256>, dim3(ny / 256, nx, 1), dim3(256), 0, 0, a, b, ny, nx, nt, nt); });
