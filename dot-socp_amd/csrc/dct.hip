@@ -142,9 +142,12 @@ __device__ __forceinline__ int bitrev(int k, int lg) { return (int)(__brev((unsi
 #define DCT_THREADS 256
 #define DCT_WAVES 4
 #define DCT_BATCH 8   // global loads in flight per lane before the first dependent LDS write
-// LDS rows are padded by one complex element every 16 (stride-16 accesses of the grouped FFT
-// stages and the bit-reversed reads then spread over the banks instead of piling onto one).
-__device__ __host__ __forceinline__ int padi(int p) { return p + (p >> 4); }
+// Position of element p inside its LDS row: the low four bits (which sixteenth of the 64 banks a 16-byte element
+// falls on) are XOR-ed with the next two groups of four bits, so that the stride-16 / stride-64 / ... accesses of the
+// grouped FFT stages AND the bit-reversed reads of the post-processing (consecutive k -> multiples of n / 16 apart)
+// spread over all banks; a permutation inside aligned blocks of 16, so rows need no padding.  (Additive padding
+// p + p / 16 left the bit-reversed reads four deep on the same banks and cost n / 16 elements per row.)
+__device__ __host__ __forceinline__ int padi(int p) { return p ^ ((p >> 4) & 15) ^ ((p >> 8) & 15); }
 __device__ __host__ __forceinline__ int row_stride(int n) { return n + (n >> 4) + 1; }
 
 // LDS hand-off between the lanes of ONE wavefront: DS operations of a wave execute in order, so
@@ -704,7 +707,7 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
 //   flight) | raw lines -> paired rows in Makhoul / natural order, in place (all reads, barrier, all writes) |
 //   [inverse pre-processing] | FFT | post-processing + stores | DMA of tile k+2 into the buffer just drained.
 // The twiddle tables live in LDS too: an ordinary global load in the loop would make the compiler wait for
-// everything in flight.  LDS: 2 x 4 x (n + n/16) x 16 B + 1.5 n x 16 B = 160 KB at n = 1024.
+// everything in flight.  LDS: 2 x 4 x (n + 1) x 16 B + 1.5 n x 16 B = 152 KB at n = 1024.
 // ---------------------------------------------------------------------------------------------
 #define PIPE_THREADS 512
 #define PIPE_IT ((1 << (PIPE_LG_CPLX - 1)) / PIPE_THREADS)   // (row, j) items per thread
@@ -722,7 +725,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
 }
 
 // the register groups of fft_rows_wg for a length known at compile time (same plan, same arithmetic)
-template <int LG, int LROWS, int T, int ST = 0, int SL = LG>
+template <int LG, int LROWS, int T, int RS, int ST = 0, int SL = LG>
 __device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, const double2 *__restrict__ tw) {
     constexpr int NST = (LG + 3) >> 2;
     constexpr int BASEB = LG / NST, EXTRA = LG % NST;
@@ -730,11 +733,10 @@ __device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, const double
         constexpr int LR = BASEB + (ST < EXTRA ? 1 : 0);
         constexpr int LPR = LG - LR;
         constexpr int TOTAL = 1 << (LROWS + LPR);
-        constexpr int RS = (1 << LG) + (1 << (LG - 4));
 #pragma unroll
         for (int b = t; b < TOTAL; b += T) dif_group<LR>(rows + (b >> LPR) * RS, SL, b & ((1 << LPR) - 1), LG, tw);
         lds_barrier();
-        fft_rows_pipe<LG, LROWS, T, ST + 1, SL - LR>(rows, t, tw);
+        fft_rows_pipe<LG, LROWS, T, RS, ST + 1, SL - LR>(rows, t, tw);
     }
 }
 
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
                                                                   const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
     constexpr int n = 1 << LG, lh = LG - 1;
-    constexpr int RS = n + (n >> 4);                  // complex elements per padded row
+    constexpr int RS = n + 1;                         // odd row stride: rows start on different banks
     constexpr int lrows = PIPE_LG_CPLX - LG;          // 2^lrows rows (pairs of lines) per tile
     constexpr int BUF = RS << lrows;                  // complex elements per buffer
     double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
@@ -763,18 +765,17 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
     const int stride = gridDim.x;
     if (tile < nTiles) dma(tile, 0);
     if (tile + stride < nTiles) dma(tile + stride, 1);
+    // the first tile has landed when only the second one's DMA is outstanding (vector-memory operations of a wave
+    // complete in issue order)
+    if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_ND) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
     // items of the staging / store loops: (row, j < n / 2), four per thread
     const int rr0 = tid >> lh, j0 = tid & ((1 << lh) - 1);
     constexpr int DRR = PIPE_THREADS >> lh;          // row step of the second item
     for (int it = 0; tile < nTiles; tile += stride, ++it) {
         const int b = it & 1;
         double2 *buf = lds + b * BUF;
-        // the DMA of this tile has landed when at most the younger operations are outstanding: the stores of the
-        // previous tile and the DMA of the next one (vector-memory operations of a wave complete in issue order)
-        if (tile + stride >= nTiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_ND) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_NS + PIPE_ND) : "memory");
-        lds_barrier();
         // raw lines (n doubles apart, unpadded) -> rows of pairs: all reads, barrier, all writes (same buffer)
         {
             const double *raw = (const double *)buf;
@@ -800,7 +801,7 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
         }
         lds_barrier();
         if (INVERSE) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwS);
-        fft_rows_pipe<LG, lrows, PIPE_THREADS>(buf, tid, twS);
+        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
         double *out = dst + ((i64)tile << (PIPE_LG_CPLX + 1));
 #pragma unroll
         for (int u = 0; u < PIPE_IT; ++u) {
@@ -819,7 +820,247 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
             *(double2 *)(out + (2 * rr) * n + 2 * j0) = Av;
             *(double2 *)(out + (2 * rr + 1) * n + 2 * j0) = Bv;
         }
-        lds_barrier();                              // the buffer is drained
+        // the next tile has landed when only this tile's stores are outstanding; one barrier then says both "every wave's
+        // pieces of the next tile are in LDS" and "this buffer is drained"
+        if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_NS) : "memory");
+        lds_barrier();
+        if (tile + 2 * stride < nTiles) dma(tile + 2 * stride, b);
+    }
+}
+
+// Strided axes, pipelined (forward / inverse): a tile = 2^lrows pairs of lines that are consecutive in memory x all n
+// elements = 4096 complex values, every (pair, k) one 16-byte access.  One 1-KB DMA piece covers 64 / NP values of k
+// for all NP pairs, so the raw LDS image is [k][pair]; the staging pass turns it into padded rows.  At n = 1024 a tile
+// is 64 bytes wide: the workgroups are ordered such that the two tiles sharing every 128-byte line run at the same
+// time on the same XCD (one fetch into its L2).
+template <int MODE /*0 fwd, 1 inv*/, int LG>
+__global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double *__restrict__ src, double *__restrict__ dst,
+                                                                    LineMap map, int nTiles, const double2 *__restrict__ tw,
+                                                                    const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    constexpr int n = 1 << LG;
+    // an ODD row stride, so that the lanes of a wave that differ in the row (staging pass, stores) fall on different banks
+    constexpr int RS = n + 1;
+    constexpr int lrows = PIPE_LG_CPLX - LG;          // log2(pairs per tile)
+    constexpr int NP = 1 << lrows;
+    constexpr int BUF = RS << lrows;
+    double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (n >> 1); i += PIPE_THREADS) twS[i] = tw[i];
+    for (int i = tid; i < n; i += PIPE_THREADS) wwS[i] = ww[i];
+    const unsigned ldsBase = (unsigned)(uintptr_t)lds;
+    // element offset of a tile's first line (the 2 NP lines of a tile are consecutive in memory: nin % (2 NP) == 0)
+    auto tile_base = [&](int tile) { return map.base((i64)tile << (lrows + 1)); };
+    const i64 laneOff = 2 * (lane & (NP - 1)) + (i64)(lane >> lrows) * map.nin;      // (pair, k) of this lane inside a piece
+    const i64 pieceStep = (i64)(64 >> lrows) * map.nin;                              // k advances by 64 / NP per piece
+    auto dma = [&](int tile, int b) {
+        const double *g = src + tile_base(tile) + laneOff + (i64)(wave * PIPE_ND) * pieceStep;
+        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16) + (unsigned)(wave * PIPE_ND) * 1024u;
+#pragma unroll
+        for (int i = 0; i < PIPE_ND; ++i) glds16(g + i * pieceStep, l0 + (unsigned)i * 1024u);
+    };
+    // tile order: workgroup w runs on XCD w % 8; the tiles 2p and 2p + 1 go to two workgroups of one XCD
+    const int w = blockIdx.x, stride = gridDim.x;     // gridDim.x is a multiple of 16
+    int tile = ((((w >> 4) << 3) + (w & 7)) << 1) | ((w >> 3) & 1);
+    if (tile < nTiles) dma(tile, 0);
+    if (tile + stride < nTiles) dma(tile + stride, 1);
+    // the first tile has landed when only the second one's DMA is outstanding (vector-memory operations of a wave
+    // complete in issue order)
+    if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_ND) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    for (int it = 0; tile < nTiles; tile += stride, ++it) {
+        const int b = it & 1;
+        double2 *buf = lds + b * BUF;
+        {
+            double vx[2 * PIPE_IT], vy[2 * PIPE_IT];
+#pragma unroll
+            for (int u = 0; u < 2 * PIPE_IT; ++u) {
+                const double2 t = buf[tid + u * PIPE_THREADS];
+                vx[u] = t.x;
+                vy[u] = t.y;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int u = 0; u < 2 * PIPE_IT; ++u) {
+                const int e = tid + u * PIPE_THREADS;
+                const int k = e >> lrows, r = e & (NP - 1);
+                buf[r * RS + padi(MODE == 1 ? k : makhoul(k, n))] = make_double2(vx[u], vy[u]);
+            }
+        }
+        lds_barrier();
+        if (MODE == 1) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwS);
+        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        {
+            // item u of this thread: pair r0, k = k0 + u * (threads / NP)
+            const int r0 = tid & (NP - 1), k0 = tid >> lrows;
+            const double2 *rr = buf + r0 * RS;
+            double *o = dst + tile_base(tile) + 2 * r0 + (i64)k0 * map.nin;
+            const i64 ostep = (i64)(PIPE_THREADS >> lrows) * map.nin;
+#pragma unroll
+            for (int u = 0; u < 2 * PIPE_IT; ++u) {
+                const int k = k0 + u * (PIPE_THREADS >> lrows);
+                double2 v;
+                if (MODE == 0) v = dct_post(rr, k, n, LG, wwS);
+                else v = rr[padi(bitrev(makhoul(k, n), LG))];
+                *(double2 *)o = v;
+                o += ostep;
+            }
+        }
+        // the next tile has landed when only this tile's stores are outstanding; one barrier then says both "every wave's
+        // pieces of the next tile are in LDS" and "this buffer is drained"
+        if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_NS) : "memory");
+        lds_barrier();
+        if (tile + 2 * stride < nTiles) dma(tile + 2 * stride, b);
+    }
+}
+
+// decimation-in-time twin of fft_rows_pipe: bit-reversed order in, natural order out (fft_rows_wave_dit's plan)
+template <int LG, int LROWS, int T, int RS, int ST = ((LG + 3) >> 2) - 1, int SL = 0>
+__device__ __forceinline__ void fft_rows_pipe_dit(double2 *rows, int t, const double2 *__restrict__ tw) {
+    constexpr int NST = (LG + 3) >> 2;
+    constexpr int BASEB = LG / NST, EXTRA = LG % NST;
+    if constexpr (ST >= 0) {
+        constexpr int LR = BASEB + (ST < EXTRA ? 1 : 0);
+        constexpr int SL2 = SL + LR;
+        constexpr int LPR = LG - LR;
+        constexpr int TOTAL = 1 << (LROWS + LPR);
+#pragma unroll
+        for (int b = t; b < TOTAL; b += T) dit_group<LR>(rows + (b >> LPR) * RS, SL2, b & ((1 << LPR) - 1), LG, tw);
+        lds_barrier();
+        fft_rows_pipe_dit<LG, LROWS, T, RS, ST - 1, SL2>(rows, t, tw);
+    }
+}
+
+// Fused t-axis solve (k_dct_strided<2>: forward DCT, division by the spectral kernel, inverse DCT), pipelined.  A tile =
+// 2^lrows pairs of consecutive columns (y, y + 1) x all n time nodes; the eigenvalue tables CY, CX, CT sit in LDS beside
+// the twiddles (no ordinary global load inside the loop).  Needs ny % (lines per tile) == 0: a tile has one x.
+template <int LG>
+__global__ void __launch_bounds__(PIPE_THREADS) k_dct_tsolve_pipe(const double *__restrict__ src, double *__restrict__ dst,
+                                                                   LineMap map, int nTiles, SolveArgs sa, int nx,
+                                                                   const double2 *__restrict__ tw,
+                                                                   const double2 *__restrict__ ww) {
+    extern __shared__ double2 lds[];
+    constexpr int n = 1 << LG, lh = LG - 1;
+    constexpr int RS = n + 1;                         // odd row stride (see k_dct_strided_pipe)
+    constexpr int lrows = PIPE_LG_CPLX - LG;
+    constexpr int NP = 1 << lrows;
+    constexpr int BUF = RS << lrows;
+    double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
+    double *ctS = (double *)(wwS + n), *cyS = ctS + n, *cxS = cyS + sa.ny;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (n >> 1); i += PIPE_THREADS) twS[i] = tw[i];
+    for (int i = tid; i < n; i += PIPE_THREADS) wwS[i] = ww[i];
+    for (int i = tid; i < n; i += PIPE_THREADS) ctS[i] = sa.ct[i];
+    for (int i = tid; i < (int)sa.ny; i += PIPE_THREADS) cyS[i] = sa.cy[i];
+    for (int i = tid; i < nx; i += PIPE_THREADS) cxS[i] = sa.cx[i];
+    const unsigned ldsBase = (unsigned)(uintptr_t)lds;
+    const i64 laneOff = 2 * (lane & (NP - 1)) + (i64)(lane >> lrows) * map.nin;
+    const i64 pieceStep = (i64)(64 >> lrows) * map.nin;
+    auto dma = [&](int tile, int b) {
+        const double *g = src + ((i64)tile << (lrows + 1)) + laneOff + (i64)(wave * PIPE_ND) * pieceStep;
+        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16) + (unsigned)(wave * PIPE_ND) * 1024u;
+#pragma unroll
+        for (int i = 0; i < PIPE_ND; ++i) glds16(g + i * pieceStep, l0 + (unsigned)i * 1024u);
+    };
+    int tile = blockIdx.x;
+    const int stride = gridDim.x;
+    if (tile < nTiles) dma(tile, 0);
+    if (tile + stride < nTiles) dma(tile + stride, 1);
+    // the first tile has landed when only the second one's DMA is outstanding (vector-memory operations of a wave
+    // complete in issue order)
+    if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_ND) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    for (int it = 0; tile < nTiles; tile += stride, ++it) {
+        const int b = it & 1;
+        double2 *buf = lds + b * BUF;
+        {   // raw [k][pair] -> rows in bit-reversed Makhoul order (the forward transform is decimation-in-time)
+            double vx[2 * PIPE_IT], vy[2 * PIPE_IT];
+#pragma unroll
+            for (int u = 0; u < 2 * PIPE_IT; ++u) {
+                const double2 t = buf[tid + u * PIPE_THREADS];
+                vx[u] = t.x;
+                vy[u] = t.y;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int u = 0; u < 2 * PIPE_IT; ++u) {
+                const int e = tid + u * PIPE_THREADS;
+                const int k = e >> lrows, r = e & (NP - 1);
+                buf[r * RS + padi(bitrev(makhoul(k, n), LG))] = make_double2(vx[u], vy[u]);
+            }
+        }
+        lds_barrier();
+        fft_rows_pipe_dit<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        // spectrum in natural order: DCT post-processing, division, inverse pre-processing on the pair (k, n - k)
+        {
+            const i64 G0 = sa.line0 + ((i64)tile << (lrows + 1));     // first column of the tile: (y0, x0)
+            const int y0 = (int)(G0 % sa.ny), x0 = (int)(G0 / sa.ny);
+            const double ex = cxS[x0];
+#pragma unroll
+            for (int u = 0; u < PIPE_IT; ++u) {
+                const int bb = tid + u * PIPE_THREADS;
+                const int rr = bb >> lh;
+                double2 *r = buf + rr * RS;
+                const double ea = cyS[y0 + 2 * rr] + ex, eb = cyS[y0 + 2 * rr + 1] + ex;
+                const int k = (bb & ((1 << lh) - 1)) + 1;          // 1 .. n/2
+                const int m = n - k;
+                const double2 vk = r[padi(k)], vm = r[padi(m)];
+                const double2 wk = wwS[k], wm = wwS[m];
+                const double ar = 0.5 * (vk.x + vm.x), ai = 0.5 * (vk.y - vm.y);
+                const double br = 0.5 * (vk.y + vm.y), bi = -0.5 * (vk.x - vm.x);
+                const double ctk = ctS[k], ctm = ctS[m];
+                double lak = ea + ctk, lbk = eb + ctk, lam = ea + ctm, lbm = eb + ctm;
+                if (lak == 0.0) lak = 1.0;
+                if (lbk == 0.0) lbk = 1.0;
+                if (lam == 0.0) lam = 1.0;
+                if (lbm == 0.0) lbm = 1.0;
+                const double2 xk = make_double2((wk.x * ar - wk.y * ai) / (sa.kscale * lak),
+                                                (wk.x * br - wk.y * bi) / (sa.kscale * lbk));
+                const double2 xm = make_double2((wm.x * ar + wm.y * ai) / (sa.kscale * lam),
+                                                (wm.x * br + wm.y * bi) / (sa.kscale * lbm));
+                const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
+                const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
+                r[padi(k)] = make_double2(gar - gbi, gai + gbr);
+                if (m != k) {
+                    const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
+                    const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
+                    r[padi(m)] = make_double2(har - hbi, hai + hbr);
+                }
+            }
+            if (tid < NP) {                                        // k = 0: V[0] is its own partner
+                const int rr = tid;
+                double2 *r = buf + rr * RS;
+                double la = (cyS[y0 + 2 * rr] + ex) + ctS[0];
+                double lb2 = (cyS[y0 + 2 * rr + 1] + ex) + ctS[0];
+                if (la == 0.0) la = 1.0;
+                if (lb2 == 0.0) lb2 = 1.0;
+                const double w0 = wwS[0].x;
+                const double2 v0 = r[0];
+                r[0] = make_double2(w0 * ((w0 * v0.x) / (sa.kscale * la)), w0 * ((w0 * v0.y) / (sa.kscale * lb2)));
+            }
+        }
+        lds_barrier();
+        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        {
+            const int r0 = tid & (NP - 1), k0 = tid >> lrows;
+            const double2 *rr = buf + r0 * RS;
+            double *o = dst + ((i64)tile << (lrows + 1)) + 2 * r0 + (i64)k0 * map.nin;
+            const i64 ostep = (i64)(PIPE_THREADS >> lrows) * map.nin;
+#pragma unroll
+            for (int u = 0; u < 2 * PIPE_IT; ++u) {
+                const int k = k0 + u * (PIPE_THREADS >> lrows);
+                *(double2 *)o = rr[padi(bitrev(makhoul(k, n), LG))];
+                o += ostep;
+            }
+        }
+        // the next tile has landed when only this tile's stores are outstanding; one barrier then says both "every wave's
+        // pieces of the next tile are in LDS" and "this buffer is drained"
+        if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_NS) : "memory");
+        lds_barrier();
         if (tile + 2 * stride < nTiles) dma(tile + 2 * stride, b);
     }
 }
@@ -1300,6 +1541,23 @@ static bool first_on_this_device(unsigned long long &done_mask) {
 
 bool dct_plan_is_pow2(const DctPlan *p) { return p->log2n > 0; }
 
+static int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+static bool dct_pipe_enabled() {
+    static const bool on = !(getenv("DOTSOCP_DCT_PIPE") && atoi(getenv("DOTSOCP_DCT_PIPE")) == 0);
+    return on;
+}
+
 static bool dct_wg_enabled() {
     static const bool on = !(getenv("DOTSOCP_DCT_WG") && atoi(getenv("DOTSOCP_DCT_WG")) == 0);
     return on;
@@ -1320,6 +1578,62 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    // fused t-axis solve, pipelined: eigenvalue tables in LDS, a tile = consecutive columns of one x
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 7 && lg <= 10 && map.outerStride == 0) {
+        const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
+        const int G = device_cus();
+        const i64 nxv = sa.ny > 0 ? sa.nplane / sa.ny : 0;
+        const size_t rs = (size_t)n + 1;
+        const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
+                               ((size_t)n + (size_t)sa.ny + (size_t)nxv) * sizeof(double);
+        if (sa.ny % tileLines == 0 && sa.line0 % tileLines == 0 && map.nLines % tileLines == 0 && nxv * sa.ny == sa.nplane &&
+            ldsPipe <= DCT_LDS_MAX && map.nLines / tileLines >= 2 * (i64)G && map.nLines / tileLines < (1ll << 30)) {
+            const int nTiles = (int)(map.nLines / tileLines);
+            static unsigned long long done_tp = 0;
+            if (first_on_this_device(done_tp)) {
+                allow_big_lds(k_dct_tsolve_pipe<7>); allow_big_lds(k_dct_tsolve_pipe<8>);
+                allow_big_lds(k_dct_tsolve_pipe<9>); allow_big_lds(k_dct_tsolve_pipe<10>);
+            }
+#define TPIPE_LAUNCH(LGV)                                                                                            \
+    hipLaunchKernelGGL((k_dct_tsolve_pipe<LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, nTiles, \
+                       sa, (int)nxv, p->tw, p->ww)
+            if (lg == 10) TPIPE_LAUNCH(10); else if (lg == 9) TPIPE_LAUNCH(9); else if (lg == 8) TPIPE_LAUNCH(8); else TPIPE_LAUNCH(7);
+#undef TPIPE_LAUNCH
+            DS_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    // pipelined persistent kernel (see k_dct_axis0_pipe): whole tiles of 4096 complex values, the chip filled twice over
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 10) {
+        const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
+        const int G = device_cus() & ~15;
+        if (map.nin % tileLines == 0 && map.nLines % tileLines == 0 && G >= 16 && map.nLines / tileLines >= 2 * (i64)G &&
+            map.nLines / tileLines < (1ll << 30)) {
+            const int nTiles = (int)(map.nLines / tileLines);
+            static unsigned long long done_sp = 0;
+            if (first_on_this_device(done_sp)) {
+                allow_big_lds(k_dct_strided_pipe<0, 7>); allow_big_lds(k_dct_strided_pipe<1, 7>);
+                allow_big_lds(k_dct_strided_pipe<0, 8>); allow_big_lds(k_dct_strided_pipe<1, 8>);
+                allow_big_lds(k_dct_strided_pipe<0, 9>); allow_big_lds(k_dct_strided_pipe<1, 9>);
+                allow_big_lds(k_dct_strided_pipe<0, 10>); allow_big_lds(k_dct_strided_pipe<1, 10>);
+            }
+            const size_t rs = (size_t)n + 1;
+            const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
+#define SPIPE_LAUNCH(M, LGV)                                                                                         \
+    hipLaunchKernelGGL((k_dct_strided_pipe<M, LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, \
+                       nTiles, p->tw, p->ww)
+            if (mode == 0) {
+                if (lg == 10) SPIPE_LAUNCH(0, 10); else if (lg == 9) SPIPE_LAUNCH(0, 9);
+                else if (lg == 8) SPIPE_LAUNCH(0, 8); else SPIPE_LAUNCH(0, 7);
+            } else {
+                if (lg == 10) SPIPE_LAUNCH(1, 10); else if (lg == 9) SPIPE_LAUNCH(1, 9);
+                else if (lg == 8) SPIPE_LAUNCH(1, 8); else SPIPE_LAUNCH(1, 7);
+            }
+#undef SPIPE_LAUNCH
+            DS_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (dct_wg_enabled() && vec && mode != 2 && ((i64)n << lp) >= 2 * DCT_WG_THREADS) {
         static unsigned long long done_wg = 0;
         if (first_on_this_device(done_wg)) {
@@ -1425,20 +1739,11 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             allow_big_lds(k_dct_axis0_wg<false>); allow_big_lds(k_dct_axis0_wg<true>);
         }
         // pipelined persistent kernel: whole tiles of 8192 doubles, enough of them to fill the chip twice
-        static const bool pipe = !(getenv("DOTSOCP_DCT_PIPE") && atoi(getenv("DOTSOCP_DCT_PIPE")) == 0);
         const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
-        if (pipe && dct_wg_enabled() && lg >= 7 && lg <= 10 && map.nLines % tileLines == 0 &&
+        if (dct_pipe_enabled() && dct_wg_enabled() && lg >= 7 && lg <= 10 && map.nLines % tileLines == 0 &&
             (((uintptr_t)src | (uintptr_t)dst) % 16 == 0)) {
-            static int cus[64] = {0};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (dev >= 0 && dev < 64 && cus[dev] == 0) {
-                int v = 0;
-                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-                cus[dev] = v;
-            }
             const i64 nTiles = map.nLines / tileLines;
-            const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+            const int ncu = device_cus();
             if (nTiles >= 2 * (i64)ncu && nTiles < (1ll << 30)) {
                 static unsigned long long done_pipe = 0;
                 if (first_on_this_device(done_pipe)) {
@@ -1447,7 +1752,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
                     allow_big_lds(k_dct_axis0_pipe<false, 9>); allow_big_lds(k_dct_axis0_pipe<true, 9>);
                     allow_big_lds(k_dct_axis0_pipe<false, 10>); allow_big_lds(k_dct_axis0_pipe<true, 10>);
                 }
-                const size_t rs = (size_t)n + (size_t)(n >> 4);
+                const size_t rs = (size_t)n + 1;
                 const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
 #define PIPE_LAUNCH(INV, LGV)                                                                                        \
     hipLaunchKernelGGL((k_dct_axis0_pipe<INV, LGV>), dim3((unsigned)ncu), dim3(PIPE_THREADS), ldsPipe, st, src, dst, \

@@ -128,7 +128,9 @@ def test_dctn_dense_lengths_through_dgemm():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("shape", [(1024, 1024, 16), (512, 2048, 8), (256, 4096, 8), (128, 8192, 8), (1024, 1023, 9)])
+@pytest.mark.parametrize("shape", [(1024, 1024, 16), (512, 2048, 8), (256, 4096, 8), (128, 8192, 8), (1024, 1023, 9),
+                                   # every length of the pipelined (LDS-DMA) kernels along every axis
+                                   (512, 512, 64), (256, 256, 256), (128, 128, 1024), (1024, 128, 128)])
 def test_dctn_many_lines(shape):
     """Many lines per axis (every workgroup of the chip busy several times over), odd line counts, dense x / t axes."""
     a = np.asfortranarray(rng.standard_normal(shape))
@@ -137,7 +139,9 @@ def test_dctn_many_lines(shape):
 
 
 @pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32), (65, 65, 33),
-                                      (129, 64, 17)])
+                                      (129, 64, 17),
+                                      # large enough for the pipelined kernels (fused t-axis solve of length 128 .. 1024)
+                                      (256, 128, 128), (128, 512, 256), (64, 512, 512), (32, 1024, 1024)])
 def test_oper_poisson(ny, nx, nt):
     Dsc = 0.37
     rhs = np.asfortranarray(rng.standard_normal((ny, nx, nt)))
