@@ -715,6 +715,18 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
 #define PIPE_NS 8         // global store instructions per wave and tile
 #define PIPE_ND 8         // LDS-DMA instructions per wave and tile (64 pieces of 1 KB over 8 waves)
 
+// A double from a wave-uniform global address through the scalar cache: no vector-memory operation, so nothing the
+// counted waits of the pipelined kernels would have to account for (the compiler takes a vector load for such a read
+// when it cannot prove that the kernel's stores leave the table alone, and then waits for everything in flight).
+__device__ __forceinline__ double sload_f64(const double *p) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
+    const double *sp = (const double *)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    double v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sp) : "memory");
+    return v;
+}
+
 // one wave-instruction: 64 lanes x 16 B from each lane's global address to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform)
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -935,27 +947,32 @@ __device__ __forceinline__ void fft_rows_pipe_dit(double2 *rows, int t, const do
 
 // Fused t-axis solve (k_dct_strided<2>: forward DCT, division by the spectral kernel, inverse DCT), pipelined.  A tile =
 // 2^lrows pairs of consecutive columns (y, y + 1) x all n time nodes; the eigenvalue tables CY, CX, CT sit in LDS beside
-// the twiddles (no ordinary global load inside the loop).  Needs ny % (lines per tile) == 0: a tile has one x.
+// the twiddles (no ordinary global load inside the loop; CX of the tile's one x is a scalar load, which the vector
+// memory counter does not see).  This pass is bound by its own chain of LDS / VALU phases (two transforms, nine
+// barriers per tile), not by HBM: tiles of 2048 values and workgroups of 256 threads, so that TWO workgroups fit a CU
+// and fill each other's gaps.  Needs ny % (lines per tile) == 0: a tile has one x.
+#define TS_THREADS 256
+#define TS_LG_CPLX 11
+#define TS_IT ((1 << (TS_LG_CPLX - 1)) / TS_THREADS)
 template <int LG>
-__global__ void __launch_bounds__(PIPE_THREADS) k_dct_tsolve_pipe(const double *__restrict__ src, double *__restrict__ dst,
-                                                                   LineMap map, int nTiles, SolveArgs sa, int nx,
+__global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__restrict__ src, double *__restrict__ dst,
+                                                                   LineMap map, int nTiles, SolveArgs sa,
                                                                    const double2 *__restrict__ tw,
                                                                    const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
     constexpr int n = 1 << LG, lh = LG - 1;
     constexpr int RS = n + 1;                         // odd row stride (see k_dct_strided_pipe)
-    constexpr int lrows = PIPE_LG_CPLX - LG;
+    constexpr int lrows = TS_LG_CPLX - LG;
     constexpr int NP = 1 << lrows;
     constexpr int BUF = RS << lrows;
     double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
-    double *ctS = (double *)(wwS + n), *cyS = ctS + n, *cxS = cyS + sa.ny;
+    double *ctS = (double *)(wwS + n), *cyS = ctS + n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < (n >> 1); i += PIPE_THREADS) twS[i] = tw[i];
-    for (int i = tid; i < n; i += PIPE_THREADS) wwS[i] = ww[i];
-    for (int i = tid; i < n; i += PIPE_THREADS) ctS[i] = sa.ct[i];
-    for (int i = tid; i < (int)sa.ny; i += PIPE_THREADS) cyS[i] = sa.cy[i];
-    for (int i = tid; i < nx; i += PIPE_THREADS) cxS[i] = sa.cx[i];
+    for (int i = tid; i < (n >> 1); i += TS_THREADS) twS[i] = tw[i];
+    for (int i = tid; i < n; i += TS_THREADS) wwS[i] = ww[i];
+    for (int i = tid; i < n; i += TS_THREADS) ctS[i] = sa.ct[i];
+    for (int i = tid; i < (int)sa.ny; i += TS_THREADS) cyS[i] = sa.cy[i];
     const unsigned ldsBase = (unsigned)(uintptr_t)lds;
     const i64 laneOff = 2 * (lane & (NP - 1)) + (i64)(lane >> lrows) * map.nin;
     const i64 pieceStep = (i64)(64 >> lrows) * map.nin;
@@ -978,31 +995,31 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_tsolve_pipe(const double *
         const int b = it & 1;
         double2 *buf = lds + b * BUF;
         {   // raw [k][pair] -> rows in bit-reversed Makhoul order (the forward transform is decimation-in-time)
-            double vx[2 * PIPE_IT], vy[2 * PIPE_IT];
+            double vx[2 * TS_IT], vy[2 * TS_IT];
 #pragma unroll
-            for (int u = 0; u < 2 * PIPE_IT; ++u) {
-                const double2 t = buf[tid + u * PIPE_THREADS];
+            for (int u = 0; u < 2 * TS_IT; ++u) {
+                const double2 t = buf[tid + u * TS_THREADS];
                 vx[u] = t.x;
                 vy[u] = t.y;
             }
             lds_barrier();
 #pragma unroll
-            for (int u = 0; u < 2 * PIPE_IT; ++u) {
-                const int e = tid + u * PIPE_THREADS;
+            for (int u = 0; u < 2 * TS_IT; ++u) {
+                const int e = tid + u * TS_THREADS;
                 const int k = e >> lrows, r = e & (NP - 1);
                 buf[r * RS + padi(bitrev(makhoul(k, n), LG))] = make_double2(vx[u], vy[u]);
             }
         }
         lds_barrier();
-        fft_rows_pipe_dit<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        fft_rows_pipe_dit<LG, lrows, TS_THREADS, RS>(buf, tid, twS);
         // spectrum in natural order: DCT post-processing, division, inverse pre-processing on the pair (k, n - k)
         {
             const i64 G0 = sa.line0 + ((i64)tile << (lrows + 1));     // first column of the tile: (y0, x0)
             const int y0 = (int)(G0 % sa.ny), x0 = (int)(G0 / sa.ny);
-            const double ex = cxS[x0];
+            const double ex = sload_f64(sa.cx + x0);
 #pragma unroll
-            for (int u = 0; u < PIPE_IT; ++u) {
-                const int bb = tid + u * PIPE_THREADS;
+            for (int u = 0; u < TS_IT; ++u) {
+                const int bb = tid + u * TS_THREADS;
                 const int rr = bb >> lh;
                 double2 *r = buf + rr * RS;
                 const double ea = cyS[y0 + 2 * rr] + ex, eb = cyS[y0 + 2 * rr + 1] + ex;
@@ -1044,15 +1061,15 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_tsolve_pipe(const double *
             }
         }
         lds_barrier();
-        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        fft_rows_pipe<LG, lrows, TS_THREADS, RS>(buf, tid, twS);
         {
             const int r0 = tid & (NP - 1), k0 = tid >> lrows;
             const double2 *rr = buf + r0 * RS;
             double *o = dst + ((i64)tile << (lrows + 1)) + 2 * r0 + (i64)k0 * map.nin;
-            const i64 ostep = (i64)(PIPE_THREADS >> lrows) * map.nin;
+            const i64 ostep = (i64)(TS_THREADS >> lrows) * map.nin;
 #pragma unroll
-            for (int u = 0; u < 2 * PIPE_IT; ++u) {
-                const int k = k0 + u * (PIPE_THREADS >> lrows);
+            for (int u = 0; u < 2 * TS_IT; ++u) {
+                const int k = k0 + u * (TS_THREADS >> lrows);
                 *(double2 *)o = rr[padi(bitrev(makhoul(k, n), LG))];
                 o += ostep;
             }
@@ -1580,23 +1597,24 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     // fused t-axis solve, pipelined: eigenvalue tables in LDS, a tile = consecutive columns of one x
     if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 7 && lg <= 10 && map.outerStride == 0) {
-        const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
-        const int G = device_cus();
+        const i64 tileLines = ((i64)2 << TS_LG_CPLX) / n;
         const i64 nxv = sa.ny > 0 ? sa.nplane / sa.ny : 0;
         const size_t rs = (size_t)n + 1;
-        const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
-                               ((size_t)n + (size_t)sa.ny + (size_t)nxv) * sizeof(double);
-        if (sa.ny % tileLines == 0 && sa.line0 % tileLines == 0 && map.nLines % tileLines == 0 && nxv * sa.ny == sa.nplane &&
-            ldsPipe <= DCT_LDS_MAX && map.nLines / tileLines >= 2 * (i64)G && map.nLines / tileLines < (1ll << 30)) {
+        const size_t ldsPipe = (2 * (rs << (TS_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
+                               ((size_t)n + (size_t)sa.ny) * sizeof(double);
+        const int G = device_cus() * (ldsPipe <= DCT_LDS_MAX / 2 ? 2 : 1);     // two workgroups per CU when they fit
+        if (tileLines >= 2 && sa.ny % tileLines == 0 && sa.line0 % tileLines == 0 && map.nLines % tileLines == 0 &&
+            nxv * sa.ny == sa.nplane && ldsPipe <= DCT_LDS_MAX && map.nLines / tileLines >= 2 * (i64)G &&
+            map.nLines / tileLines < (1ll << 30)) {
             const int nTiles = (int)(map.nLines / tileLines);
             static unsigned long long done_tp = 0;
             if (first_on_this_device(done_tp)) {
                 allow_big_lds(k_dct_tsolve_pipe<7>); allow_big_lds(k_dct_tsolve_pipe<8>);
                 allow_big_lds(k_dct_tsolve_pipe<9>); allow_big_lds(k_dct_tsolve_pipe<10>);
             }
-#define TPIPE_LAUNCH(LGV)                                                                                            \
-    hipLaunchKernelGGL((k_dct_tsolve_pipe<LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, nTiles, \
-                       sa, (int)nxv, p->tw, p->ww)
+#define TPIPE_LAUNCH(LGV)                                                                                              \
+    hipLaunchKernelGGL((k_dct_tsolve_pipe<LGV>), dim3((unsigned)G), dim3(TS_THREADS), ldsPipe, st, src, dst, map, nTiles, sa, \
+                       p->tw, p->ww)
             if (lg == 10) TPIPE_LAUNCH(10); else if (lg == 9) TPIPE_LAUNCH(9); else if (lg == 8) TPIPE_LAUNCH(8); else TPIPE_LAUNCH(7);
 #undef TPIPE_LAUNCH
             DS_HIP(hipGetLastError());
