@@ -145,6 +145,52 @@ __global__ void __launch_bounds__(64 * XB) soa8s(const double *in, double *out, 
     }
 }
 
+// soa8c fed by LDS-DMA: the ten planes of a step arrive in an LDS ring D steps deep (global_load_lds_dwordx4, no
+// registers held by loads in flight), the lanes read their values from LDS, scale and store.  Does a marching tile
+// get closer to the copy rate when two or three steps of loads are always in flight?
+__device__ __forceinline__ void glds16p(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int D>
+__global__ void __launch_bounds__(256) soa8dma(const double *in, double *out, i64 ny, i64 nx, i64 nt, i64 tc) {
+    extern __shared__ double ring[];                 // [D][10][4][64]
+    const int lane = threadIdx.x, xl = threadIdx.y, tid = xl * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), l64 = tid & 63;
+    const i64 y0 = (i64)blockIdx.x * 64, x0 = (i64)blockIdx.y * 4;
+    const i64 Nz = ny * nx * nt;
+    const i64 t0 = blockIdx.z * tc, t1 = (t0 + tc < nt) ? t0 + tc : nt;
+    const unsigned base = (unsigned)(uintptr_t)ring;
+    // piece q = plane * 2 + half (20 per step, 5 per wave): lanes 0..31 column 2 half, lanes 32..63 column 2 half + 1
+    auto dma = [&](i64 t, int slot) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wave * 5 + i, plane = q >> 1, half = q & 1;
+            const i64 col = x0 + 2 * half + (l64 >> 5);
+            const double *g = in + plane * Nz + y0 + ny * (col + nx * t) + 2 * (l64 & 31);
+            glds16p(g, base + (unsigned)(((slot * 10 + plane) * 4 + 2 * half) * 64) * 8u);
+        }
+    };
+    for (int d = 0; d < D - 1; ++d)
+        if (t0 + d < t1) dma(t0 + d, d);
+    for (i64 t = t0; t < t1; ++t) {
+        const int slot = (int)((t - t0) % D);
+        if (t + D - 1 < t1) dma(t + D - 1, (int)((t - t0 + D - 1) % D));
+        // DMA(t) done when at most the younger operations are outstanding (steady state): see the text above
+        if (t + D - 1 < t1 && t - t0 >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * 5 + (D - 1) * 10 > 63 ? 63 : (D - 1) * 5 + (D - 1) * 10) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const i64 i = y0 + lane + ny * (x0 + xl + nx * t);
+        double v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = ring[((slot * 10 + j) * 4 + xl) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) out[j * Nz + i] = v[j] * 1.0001;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // slot read by everyone before it is refilled
+    }
+}
+
 template <class F>
 static double timeit(F f, int reps = 5) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -187,6 +233,18 @@ int main() {
     for (i64 skew : {(i64)16, (i64)528, (i64)4112}) {
         ms = timeit([&] { hipLaunchKernelGGL(soa8s<4>, dim3(ny / 64, nx / 4, 8), dim3(64, 4), 0, 0, a, b + skew, ny, nx, nt, (i64)16, Nz); });
         printf("soa8s 64x4 tile, 8 chunks, out shifted by %5lld doubles    : %.3f ms  %.0f GB/s\n", skew, ms, gb / ms * 1e3);
+    }
+    hipFuncSetAttribute((const void *)soa8dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void *)soa8dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void *)soa8dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (i64 tcv : {(i64)16, (i64)32, (i64)127}) {
+        const unsigned nz = (unsigned)((nt + tcv - 1) / tcv);
+        ms = timeit([&] { hipLaunchKernelGGL(soa8dma<2>, dim3(ny / 64, nx / 4, nz), dim3(64, 4), 2 * 20480, 0, a, b, ny, nx, nt, tcv); });
+        printf("soa8dma ring 2, chunks of %3lld   : %.3f ms  %.0f GB/s\n", tcv, ms, gb / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL(soa8dma<3>, dim3(ny / 64, nx / 4, nz), dim3(64, 4), 3 * 20480, 0, a, b, ny, nx, nt, tcv); });
+        printf("soa8dma ring 3, chunks of %3lld   : %.3f ms  %.0f GB/s\n", tcv, ms, gb / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL(soa8dma<4>, dim3(ny / 64, nx / 4, nz), dim3(64, 4), 4 * 20480, 0, a, b, ny, nx, nt, tcv); });
+        printf("soa8dma ring 4, chunks of %3lld   : %.3f ms  %.0f GB/s\n", tcv, ms, gb / ms * 1e3);
     }
     ms = timeit([&] { hipLaunchKernelGGL(soa8p<4>, dim3(ny / 64, nx / 4), dim3(64, 4), 0, 0, a, b, ny, nx, nt); });
     printf("soa8p 64x4 tile, prefetch next: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
