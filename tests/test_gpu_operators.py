@@ -130,7 +130,10 @@ def test_dctn_dense_lengths_through_dgemm():
 
 @pytest.mark.parametrize("shape", [(1024, 1024, 16), (512, 2048, 8), (256, 4096, 8), (128, 8192, 8), (1024, 1023, 9),
                                    # every length of the pipelined (LDS-DMA) kernels along every axis
-                                   (512, 512, 64), (256, 256, 256), (128, 128, 1024), (1024, 128, 128)])
+                                   (512, 512, 64), (256, 256, 256), (128, 128, 1024), (1024, 128, 128),
+                                   # tile counts that do not divide by the persistent grid: workgroups with two and with
+                                   # three tiles (first / steady / last wait counts of the LDS-DMA pipeline)
+                                   (1024, 1024, 5), (512, 1024, 9)])
 def test_dctn_many_lines(shape):
     """Many lines per axis (every workgroup of the chip busy several times over), odd line counts, dense x / t axes."""
     a = np.asfortranarray(rng.standard_normal(shape))
@@ -141,7 +144,8 @@ def test_dctn_many_lines(shape):
 @pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32), (65, 65, 33),
                                       (129, 64, 17),
                                       # large enough for the pipelined kernels (fused t-axis solve of length 128 .. 1024)
-                                      (256, 128, 128), (128, 512, 256), (64, 512, 512), (32, 1024, 1024)])
+                                      (256, 128, 128), (128, 512, 256), (64, 512, 512), (32, 1024, 1024),
+                                      (256, 160, 128), (64, 1000, 128)])        # tile counts that leave a remainder
 def test_oper_poisson(ny, nx, nt):
     Dsc = 0.37
     rhs = np.asfortranarray(rng.standard_normal((ny, nx, nt)))
@@ -153,3 +157,32 @@ def test_oper_poisson(ny, nx, nt):
         ref = oper_poisson(kernel, rhs).ravel(order="F")
     got = D.oper_poisson3dim(Dsc ** 2, rhs)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def test_pipelined_dct_kernels_against_the_workgroup_wide_ones():
+    """DOTSOCP_DCT_PIPE=0 (read once per process, hence the subprocesses) switches the persistent LDS-DMA kernels off; both
+    families run the same butterflies on the same operands, so transforms and Poisson solves agree to rounding of the
+    few places where the order of operations differs (none in the transforms: identical bits expected there)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np, dotsocp_amd as D\n"
+        "rng = np.random.default_rng(11)\n"
+        "a = np.asfortranarray(rng.standard_normal((1024, 512, 16)))\n"
+        "b = np.asfortranarray(rng.standard_normal((256, 256, 128)))\n"
+        "np.savez(sys.argv[1], f=D.mirt_dctn(a), i=D.mirt_idctn(a), p=D.oper_poisson3dim(0.37 ** 2, b))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for flag in ("0", "1"):
+            path = os.path.join(tmp, f"dct{flag}.npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DOTSOCP_DCT_PIPE=flag), cwd=root,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            with np.load(path) as z:
+                out[flag] = {k: z[k].copy() for k in z.files}
+    np.testing.assert_array_equal(out["1"]["f"], out["0"]["f"])
+    np.testing.assert_array_equal(out["1"]["i"], out["0"]["i"])
+    np.testing.assert_allclose(out["1"]["p"], out["0"]["p"], rtol=0, atol=1e-13 * np.abs(out["0"]["p"]).max())
