@@ -129,6 +129,27 @@ __global__ void __launch_bounds__(64 * XB) aosoa8(const double *in, double *out,
     }
 }
 
+// soa8c as a persistent kernel: `gridDim.x` workgroups walk the (tile, chunk) units in dispatch order, so that the
+// resident workgroups stay on neighbouring tiles of the same layers (a ragged dispatch spreads them over many layers)
+template <int XB>
+__global__ void __launch_bounds__(64 * XB) soa8pers(const double *in, double *out, i64 ny, i64 nx, i64 nt, i64 tc) {
+    const i64 nyb = ny / 64, nxb = nx / XB, nzb = (nt + tc - 1) / tc;
+    const i64 Nz = ny * nx * nt;
+    for (i64 u = blockIdx.x; u < nyb * nxb * nzb; u += gridDim.x) {
+        const i64 by = u % nyb, bx = (u / nyb) % nxb, bz = u / (nyb * nxb);
+        const i64 y = by * 64 + threadIdx.x, x = bx * XB + threadIdx.y;
+        const i64 t0 = bz * tc, t1 = (t0 + tc < nt) ? t0 + tc : nt;
+        for (i64 t = t0; t < t1; ++t) {
+            const i64 i = y + ny * (x + nx * t);
+            double v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = in[j * Nz + i];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) out[j * Nz + i] = v[j] * 1.0001;
+        }
+    }
+}
+
 // soa8c with a plane stride that differs from the plane length (ps doubles between the planes of in / out, `skew` more
 // between in and out): do the ten streams of a wave collide on HBM channels when the planes are a multiple of 8 MiB apart?
 template <int XB>
@@ -234,6 +255,14 @@ int main() {
         ms = timeit([&] { hipLaunchKernelGGL(soa8s<4>, dim3(ny / 64, nx / 4, 8), dim3(64, 4), 0, 0, a, b + skew, ny, nx, nt, (i64)16, Nz); });
         printf("soa8s 64x4 tile, 8 chunks, out shifted by %5lld doubles    : %.3f ms  %.0f GB/s\n", skew, ms, gb / ms * 1e3);
     }
+    for (unsigned wgs : {1024u, 2048u, 4096u}) {
+        ms = timeit([&] { hipLaunchKernelGGL(soa8pers<4>, dim3(wgs), dim3(64, 4), 0, 0, a, b, ny, nx, nt, (i64)16); });
+        printf("soa8pers 64x4, 16-layer chunks, %4u persistent workgroups: %.3f ms  %.0f GB/s\n", wgs, ms, gb / ms * 1e3);
+    }
+    ms = timeit([&] { hipLaunchKernelGGL(soa8pers<4>, dim3(2048), dim3(64, 4), 0, 0, a, b, ny, nx, nt, (i64)4); });
+    printf("soa8pers 64x4,  4-layer chunks, 2048 persistent workgroups: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
+    ms = timeit([&] { hipLaunchKernelGGL(soa8pers<4>, dim3(2048), dim3(64, 4), 0, 0, a, b, ny, nx, nt, (i64)127); });
+    printf("soa8pers 64x4, whole-t chunks,  2048 persistent workgroups: %.3f ms  %.0f GB/s\n", ms, gb / ms * 1e3);
     hipFuncSetAttribute((const void *)soa8dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void *)soa8dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void *)soa8dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
