@@ -59,6 +59,7 @@ struct Slab {
     hipStream_t st_z = nullptr; // second stream: cone pass / middle q-step chunks when they overlap the rest
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_halo = nullptr;
     hipEvent_t xev[DS_XEV] = {nullptr};   // ordering of cross-slab copies (Solver::xcopy), used round-robin
+    hipEvent_t ev_tri = nullptr;          // "this slab's interface message is written" (Solver::tri_exchange, slabs of one process)
     int xev_next = 0;
     DevRes *res = nullptr;      // plans / tables of `dev`
     double *h_sums = nullptr;   // pinned host copy of this slab's KKT partial sums [S_COUNT]

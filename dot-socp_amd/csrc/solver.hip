@@ -145,6 +145,7 @@ void Solver::free_slabs() {
         if (s.st_z) (void)hipStreamSynchronize(s.st_z);
         if (s.st) (void)hipStreamSynchronize(s.st);
         for (auto &e : s.xev) if (e) (void)hipEventDestroy(e);
+        if (s.ev_tri) (void)hipEventDestroy(s.ev_tri);
         if (s.st != stream) {        // slab 0 borrows the solver's own streams / events
             if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
             if (s.ev_join) (void)hipEventDestroy(s.ev_join);
@@ -298,6 +299,7 @@ int Solver::alloc_slabs(int first, int count) {
             DS_HIP(hipEventCreateWithFlags(&s.ev_halo, hipEventDisableTiming));
         }
         for (auto &e : s.xev) DS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DS_HIP(hipEventCreateWithFlags(&s.ev_tri, hipEventDisableTiming));
         DS_HIP(hipHostMalloc((void **)&s.h_sums, sizeof(double) * S_COUNT));
         s.res = res_for(s.dev);
         if (!s.res) return DOTSOCP_EHIP;
@@ -616,6 +618,34 @@ int Solver::tri_exchange(bool back) {
     auto off = [&](int j) { return 2 * pc.cut[j] + (i64)TRI_EXTRA * j; };                  // in tri_send / tri_brecv
     auto cnt = [&](int j) { return 2 * (pc.cut[j + 1] - pc.cut[j]) + (i64)TRI_EXTRA; };  // message for / from owner j
     if (!remote()) {
+        // Slabs of one process: every receiver pulls all its messages with ONE launch (peer pointers; P launches and
+        // P * P stream waits instead of P * P event-ordered copies, whose host cost grew to 2.8 ms per iteration at
+        // eight slabs).  "Message written" is one event per slab; the buffers need no event for their reuse: a sender
+        // overwrites its message only behind its own next gather, which waits for every receiver of this one.
+        static const bool gather = !(getenv("DOTSOCP_TRI_GATHER") && atoi(getenv("DOTSOCP_TRI_GATHER")) == 0);
+        if (gather) {
+            FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_tri, s.st));
+            FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
+                GatherMsgs m{};
+                m.n = 0;
+                for (auto &ss : slabs) {    // sender
+                    if (ss.st != sd.st) DS_HIP(hipStreamWaitEvent(sd.st, ss.ev_tri, 0));
+                    const int d = sd.index, q = ss.index;
+                    if (!back) {            // slab q's message for owner d
+                        m.src[m.n] = ss.tri_send + off(d);
+                        m.dst_off[m.n] = (i64)q * cnt(d);
+                        m.count[m.n] = cnt(d);
+                    } else {                // owner q's answer for slab d
+                        m.src[m.n] = ss.tri_bsend + (i64)d * cnt(q);
+                        m.dst_off[m.n] = off(q);
+                        m.count[m.n] = cnt(q);
+                    }
+                    ++m.n;
+                }
+                DS_CHECK(launch_gather_msgs(m, back ? sd.tri_brecv : sd.tri_recv, sd.st));
+            }
+            return 0;
+        }
         for (auto &sp : slabs)             // slab p
             for (auto &sj : slabs) {       // owner j
                 const int p = sp.index, j = sj.index;
