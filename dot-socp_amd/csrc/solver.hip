@@ -622,7 +622,8 @@ int Solver::tri_exchange(bool back) {
         // P * P stream waits instead of P * P event-ordered copies, whose host cost grew to 2.8 ms per iteration at
         // eight slabs).  "Message written" is one event per slab; the buffers need no event for their reuse: a sender
         // overwrites its message only behind its own next gather, which waits for every receiver of this one.
-        static const bool gather = !(getenv("DOTSOCP_TRI_GATHER") && atoi(getenv("DOTSOCP_TRI_GATHER")) == 0);
+        const char *ge = getenv("DOTSOCP_TRI_GATHER");            // read per call: the tests switch it inside one process
+        const bool gather = !(ge && atoi(ge) == 0);
         if (gather) {
             FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_tri, s.st));
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
