@@ -178,7 +178,9 @@ __device__ __forceinline__ double2 mul_w16(double2 d, int t) {
 // R = 2^LR elements base + m * (S/R) of one sub-transform of span S = 2^sl and performs the
 // butterflies of spans S, S/2, ..., S/2^(LR-1) on them (same data flow as LR passes of the
 // textbook in-place radix-2 DIF, so the output order is plain bit reversal).
-template <int LR>
+// LES > 0: the rows of a tile are interleaved element by element (element p of row r at (padi(p) << LES) + r, `row`
+// = tile + r) -- the image an LDS-DMA piece leaves when each lane fetches one (pair, k) element; LES = 0: plain rows
+template <int LR, int LES = 0>
 __device__ __forceinline__ void dif_group(double2 *__restrict__ row, int sl, int bidx, int lg,
                                           const double2 *__restrict__ tw) {
     constexpr int R = 1 << LR;
@@ -187,7 +189,7 @@ __device__ __forceinline__ void dif_group(double2 *__restrict__ row, int sl, int
     const int base = ((bidx >> strideLog) << sl) + j;
     double2 x[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) x[m] = row[padi(base + (m << strideLog))];
+    for (int m = 0; m < R; ++m) x[m] = row[padi(base + (m << strideLog)) << LES];
     const int tj = j << (lg - sl);   // j * N / S
 #pragma unroll
     for (int u = 0; u < LR; ++u) {
@@ -205,7 +207,7 @@ __device__ __forceinline__ void dif_group(double2 *__restrict__ row, int sl, int
         }
     }
 #pragma unroll
-    for (int m = 0; m < R; ++m) row[padi(base + (m << strideLog))] = x[m];
+    for (int m = 0; m < R; ++m) row[padi(base + (m << strideLog)) << LES] = x[m];
 }
 
 // FFT of the `nrows` = 2^lrw complex rows (length n = 2^lg) owned by the CALLING WAVE, in LDS:
@@ -238,7 +240,7 @@ __device__ __forceinline__ void fft_rows_wave(double2 *rows, int lrw, int lg, in
 // Decimation-in-time twin of dif_group: same element set (base + m * S/R), the butterflies of spans S/2^(LR-1),
 // ..., S/2, S in INCREASING order with the twiddle applied before the add / subtract -- bit-reversed input,
 // natural-order output.  Used where the spectrum is needed in place in natural order (fused t-axis solve).
-template <int LR>
+template <int LR, int LES = 0>
 __device__ __forceinline__ void dit_group(double2 *__restrict__ row, int sl, int bidx, int lg,
                                           const double2 *__restrict__ tw) {
     constexpr int R = 1 << LR;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void dit_group(double2 *__restrict__ row, int sl, int
     const int base = ((bidx >> strideLog) << sl) + j;
     double2 x[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) x[m] = row[padi(base + (m << strideLog))];
+    for (int m = 0; m < R; ++m) x[m] = row[padi(base + (m << strideLog)) << LES];
     const int tj = j << (lg - sl);   // j * N / S
 #pragma unroll
     for (int u = LR - 1; u >= 0; --u) {
@@ -264,7 +266,7 @@ __device__ __forceinline__ void dit_group(double2 *__restrict__ row, int sl, int
         }
     }
 #pragma unroll
-    for (int m = 0; m < R; ++m) row[padi(base + (m << strideLog))] = x[m];
+    for (int m = 0; m < R; ++m) row[padi(base + (m << strideLog)) << LES] = x[m];
 }
 
 // FFT of the calling wave's rows, bit-reversed order in, natural order out (the register groups of
@@ -336,10 +338,11 @@ __device__ __forceinline__ void idct_combine_wave(double2 *rows, int lrw, int lg
 
 // (Xa[k], Xb[k]) = real(ww[k] * V_{a,b}[k]) from the bit-reversed FFT of va + i vb:
 // V_a = (V[k] + conj(V[n-k])) / 2, V_b = (V[k] - conj(V[n-k])) / (2i)   (mirt_dctn.m:130)
+template <int LES = 0>
 __device__ __forceinline__ double2 dct_post(const double2 *__restrict__ r, int k, int n, int lg,
                                             const double2 *__restrict__ ww) {
-    const double2 vk = r[padi(bitrev(k, lg))];
-    const double2 vm = r[padi(bitrev((n - k) & (n - 1), lg))];
+    const double2 vk = r[padi(bitrev(k, lg)) << LES];
+    const double2 vm = r[padi(bitrev((n - k) & (n - 1), lg)) << LES];
     const double2 w = ww[k];
     const double ar = 0.5 * (vk.x + vm.x), ai = 0.5 * (vk.y - vm.y);
     const double br = 0.5 * (vk.y + vm.y), bi = -0.5 * (vk.x - vm.x);
@@ -737,6 +740,70 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
 }
 
 // the register groups of fft_rows_wg for a length known at compile time (same plan, same arithmetic)
+// the same register groups on a pair-interleaved tile (dif_group<., LES>): item b = (row b % rows, group b / rows), so the
+// lanes of a wave sweep the rows of one element first -- consecutive LDS addresses
+template <int LG, int LROWS, int T, int ST = 0, int SL = LG>
+__device__ __forceinline__ void fft_tile_pipe(double2 *tile, int t, const double2 *__restrict__ tw) {
+    constexpr int NST = (LG + 3) >> 2;
+    constexpr int BASEB = LG / NST, EXTRA = LG % NST;
+    if constexpr (ST < NST) {
+        constexpr int LR = BASEB + (ST < EXTRA ? 1 : 0);
+        constexpr int LPR = LG - LR;
+        constexpr int TOTAL = 1 << (LROWS + LPR);
+#pragma unroll
+        for (int b = t; b < TOTAL; b += T)
+            dif_group<LR, LROWS>(tile + (b & ((1 << LROWS) - 1)), SL, b >> LROWS, LG, tw);
+        lds_barrier();
+        fft_tile_pipe<LG, LROWS, T, ST + 1, SL - LR>(tile, t, tw);
+    }
+}
+
+template <int LG, int LROWS, int T, int ST = ((LG + 3) >> 2) - 1, int SL = 0>
+__device__ __forceinline__ void fft_tile_pipe_dit(double2 *tile, int t, const double2 *__restrict__ tw) {
+    constexpr int NST = (LG + 3) >> 2;
+    constexpr int BASEB = LG / NST, EXTRA = LG % NST;
+    if constexpr (ST >= 0) {
+        constexpr int LR = BASEB + (ST < EXTRA ? 1 : 0);
+        constexpr int SL2 = SL + LR;
+        constexpr int LPR = LG - LR;
+        constexpr int TOTAL = 1 << (LROWS + LPR);
+#pragma unroll
+        for (int b = t; b < TOTAL; b += T)
+            dit_group<LR, LROWS>(tile + (b & ((1 << LROWS) - 1)), SL2, b >> LROWS, LG, tw);
+        lds_barrier();
+        fft_tile_pipe_dit<LG, LROWS, T, ST - 1, SL2>(tile, t, tw);
+    }
+}
+
+// inverse pre-processing (idct_combine_wg) on a pair-interleaved tile
+template <int LG, int LROWS, int T>
+__device__ __forceinline__ void idct_combine_tile(double2 *tile, int t, const double2 *__restrict__ ww) {
+    constexpr int n = 1 << LG, lh = LG - 1;
+    constexpr int TOTAL = 1 << (LROWS + lh);
+#pragma unroll
+    for (int b = t; b < TOTAL; b += T) {
+        double2 *r = tile + (b & ((1 << LROWS) - 1));
+        const int k = (b >> LROWS) + 1;                     // 1 .. n/2
+        const int m = n - k;
+        const int ik = padi(k) << LROWS, im = padi(m) << LROWS;
+        const double2 xk = r[ik], xm = r[im];
+        const double2 wk = ww[k], wm = ww[m];
+        const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
+        const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
+        r[ik] = make_double2(gar - gbi, gai + gbr);
+        if (m != k) {
+            const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
+            const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
+            r[im] = make_double2(har - hbi, hai + hbr);
+        }
+    }
+    if (t < (1 << LROWS)) {
+        const double w0 = ww[0].x;
+        tile[t] = make_double2(w0 * tile[t].x, w0 * tile[t].y);
+    }
+    lds_barrier();
+}
+
 template <int LG, int LROWS, int T, int RS, int ST = 0, int SL = LG>
 __device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, const double2 *__restrict__ tw) {
     constexpr int NST = (LG + 3) >> 2;
@@ -841,21 +908,22 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
 }
 
 // Strided axes, pipelined (forward / inverse): a tile = 2^lrows pairs of lines that are consecutive in memory x all n
-// elements = 4096 complex values, every (pair, k) one 16-byte access.  One 1-KB DMA piece covers 64 / NP values of k
-// for all NP pairs, so the raw LDS image is [k][pair]; the staging pass turns it into padded rows.  At n = 1024 a tile
-// is 64 bytes wide: the workgroups are ordered such that the two tiles sharing every 128-byte line run at the same
-// time on the same XCD (one fetch into its L2).
+// elements = 4096 complex values, every (pair, k) one 16-byte access.  The tile lives in LDS pair-interleaved and in the
+// order the transform wants: slot (padi(p) << lrows) + r holds position p of pair r, i.e. line element k = 2 p resp.
+// 2 (n - 1 - p) + 1 (Makhoul order, forward) or k = p (inverse).  An LDS-DMA piece fills 64 consecutive slots = 64 / NP
+// positions of all NP pairs: each lane fetches its own (pair, k) element, a piece still reads 64 / NP whole segments of
+// NP x 16 bytes, and the tile is ready for the first butterfly group when it has landed -- no staging pass.  At
+// n = 1024 a tile is 64 bytes wide: the workgroups are ordered such that the two tiles sharing every 128-byte line run
+// at the same time on the same XCD (one fetch into its L2).
 template <int MODE /*0 fwd, 1 inv*/, int LG>
 __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double *__restrict__ src, double *__restrict__ dst,
                                                                     LineMap map, int nTiles, const double2 *__restrict__ tw,
                                                                     const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
     constexpr int n = 1 << LG;
-    // an ODD row stride, so that the lanes of a wave that differ in the row (staging pass, stores) fall on different banks
-    constexpr int RS = n + 1;
     constexpr int lrows = PIPE_LG_CPLX - LG;          // log2(pairs per tile)
     constexpr int NP = 1 << lrows;
-    constexpr int BUF = RS << lrows;
+    constexpr int BUF = 1 << PIPE_LG_CPLX;            // complex elements per buffer (no padding: the swizzle permutes)
     double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -864,13 +932,16 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
     const unsigned ldsBase = (unsigned)(uintptr_t)lds;
     // element offset of a tile's first line (the 2 NP lines of a tile are consecutive in memory: nin % (2 NP) == 0)
     auto tile_base = [&](int tile) { return map.base((i64)tile << (lrows + 1)); };
-    const i64 laneOff = 2 * (lane & (NP - 1)) + (i64)(lane >> lrows) * map.nin;      // (pair, k) of this lane inside a piece
-    const i64 pieceStep = (i64)(64 >> lrows) * map.nin;                              // k advances by 64 / NP per piece
     auto dma = [&](int tile, int b) {
-        const double *g = src + tile_base(tile) + laneOff + (i64)(wave * PIPE_ND) * pieceStep;
-        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16) + (unsigned)(wave * PIPE_ND) * 1024u;
+        const double *g0 = src + tile_base(tile) + 2 * (lane & (NP - 1));
+        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16);
 #pragma unroll
-        for (int i = 0; i < PIPE_ND; ++i) glds16(g + i * pieceStep, l0 + (unsigned)i * 1024u);
+        for (int i = 0; i < PIPE_ND; ++i) {
+            const int c = wave * PIPE_ND + i;                         // piece: slots 64 c .. 64 c + 63
+            const int p = padi(((c << 6) + lane) >> lrows);          // position held by this lane's slot
+            const int k = (MODE == 1) ? p : ((p < (n >> 1)) ? 2 * p : 2 * (n - 1 - p) + 1);
+            glds16(g0 + (i64)k * map.nin, l0 + (unsigned)c * 1024u);
+        }
     };
     // tile order: workgroup w runs on XCD w % 8; the tiles 2p and 2p + 1 go to two workgroups of one XCD
     const int w = blockIdx.x, stride = gridDim.x;     // gridDim.x is a multiple of 16
@@ -885,37 +956,20 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
     for (int it = 0; tile < nTiles; tile += stride, ++it) {
         const int b = it & 1;
         double2 *buf = lds + b * BUF;
-        {
-            double vx[2 * PIPE_IT], vy[2 * PIPE_IT];
-#pragma unroll
-            for (int u = 0; u < 2 * PIPE_IT; ++u) {
-                const double2 t = buf[tid + u * PIPE_THREADS];
-                vx[u] = t.x;
-                vy[u] = t.y;
-            }
-            lds_barrier();
-#pragma unroll
-            for (int u = 0; u < 2 * PIPE_IT; ++u) {
-                const int e = tid + u * PIPE_THREADS;
-                const int k = e >> lrows, r = e & (NP - 1);
-                buf[r * RS + padi(MODE == 1 ? k : makhoul(k, n))] = make_double2(vx[u], vy[u]);
-            }
-        }
-        lds_barrier();
-        if (MODE == 1) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwS);
-        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        if (MODE == 1) idct_combine_tile<LG, lrows, PIPE_THREADS>(buf, tid, wwS);
+        fft_tile_pipe<LG, lrows, PIPE_THREADS>(buf, tid, twS);
         {
             // item u of this thread: pair r0, k = k0 + u * (threads / NP)
             const int r0 = tid & (NP - 1), k0 = tid >> lrows;
-            const double2 *rr = buf + r0 * RS;
+            const double2 *rr = buf + r0;
             double *o = dst + tile_base(tile) + 2 * r0 + (i64)k0 * map.nin;
             const i64 ostep = (i64)(PIPE_THREADS >> lrows) * map.nin;
 #pragma unroll
             for (int u = 0; u < 2 * PIPE_IT; ++u) {
                 const int k = k0 + u * (PIPE_THREADS >> lrows);
                 double2 v;
-                if (MODE == 0) v = dct_post(rr, k, n, LG, wwS);
-                else v = rr[padi(bitrev(makhoul(k, n), LG))];
+                if (MODE == 0) v = dct_post<lrows>(rr, k, n, LG, wwS);
+                else v = rr[padi(bitrev(makhoul(k, n), LG)) << lrows];
                 *(double2 *)o = v;
                 o += ostep;
             }
@@ -928,43 +982,27 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
     }
 }
 
-// decimation-in-time twin of fft_rows_pipe: bit-reversed order in, natural order out (fft_rows_wave_dit's plan)
-template <int LG, int LROWS, int T, int RS, int ST = ((LG + 3) >> 2) - 1, int SL = 0>
-__device__ __forceinline__ void fft_rows_pipe_dit(double2 *rows, int t, const double2 *__restrict__ tw) {
-    constexpr int NST = (LG + 3) >> 2;
-    constexpr int BASEB = LG / NST, EXTRA = LG % NST;
-    if constexpr (ST >= 0) {
-        constexpr int LR = BASEB + (ST < EXTRA ? 1 : 0);
-        constexpr int SL2 = SL + LR;
-        constexpr int LPR = LG - LR;
-        constexpr int TOTAL = 1 << (LROWS + LPR);
-#pragma unroll
-        for (int b = t; b < TOTAL; b += T) dit_group<LR>(rows + (b >> LPR) * RS, SL2, b & ((1 << LPR) - 1), LG, tw);
-        lds_barrier();
-        fft_rows_pipe_dit<LG, LROWS, T, RS, ST - 1, SL2>(rows, t, tw);
-    }
-}
-
 // Fused t-axis solve (k_dct_strided<2>: forward DCT, division by the spectral kernel, inverse DCT), pipelined.  A tile =
-// 2^lrows pairs of consecutive columns (y, y + 1) x all n time nodes; the eigenvalue tables CY, CX, CT sit in LDS beside
-// the twiddles (no ordinary global load inside the loop; CX of the tile's one x is a scalar load, which the vector
-// memory counter does not see).  This pass is bound by its own chain of LDS / VALU phases (two transforms, nine
-// barriers per tile), not by HBM: tiles of 2048 values and workgroups of 256 threads, so that TWO workgroups fit a CU
+// 2^lrows pairs of consecutive columns (y, y + 1) x all n time nodes, pair-interleaved in LDS like the strided kernel's;
+// the eigenvalue tables CY, CT sit in LDS beside the twiddles (no ordinary global load inside the loop; CX of the tile's
+// one x is a scalar load, which the vector memory counter does not see).  This pass is bound by its own chain of LDS /
+// VALU phases (two transforms, seven barriers per tile), not by HBM: tiles of 2048 values and workgroups of 256 threads, so that TWO workgroups fit a CU
 // and fill each other's gaps.  Needs ny % (lines per tile) == 0: a tile has one x.
 #define TS_THREADS 256
 #define TS_LG_CPLX 11
 #define TS_IT ((1 << (TS_LG_CPLX - 1)) / TS_THREADS)
 template <int LG>
 __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__restrict__ src, double *__restrict__ dst,
-                                                                   LineMap map, int nTiles, SolveArgs sa,
-                                                                   const double2 *__restrict__ tw,
-                                                                   const double2 *__restrict__ ww) {
+                                                                 LineMap map, int nTiles, SolveArgs sa,
+                                                                 const double2 *__restrict__ tw,
+                                                                 const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
-    constexpr int n = 1 << LG, lh = LG - 1;
-    constexpr int RS = n + 1;                         // odd row stride (see k_dct_strided_pipe)
+    constexpr int n = 1 << LG;
     constexpr int lrows = TS_LG_CPLX - LG;
     constexpr int NP = 1 << lrows;
-    constexpr int BUF = RS << lrows;
+    constexpr int BUF = 1 << TS_LG_CPLX;              // pair-interleaved tile (see k_dct_strided_pipe), no padding
+    constexpr int TS_ND = (1 << (TS_LG_CPLX - 6)) / (TS_THREADS / 64);     // DMA pieces per wave and tile
+    static_assert(TS_ND == PIPE_ND && (1 << TS_LG_CPLX) / TS_THREADS == PIPE_NS, "wait counts are shared with the other pipes");
     double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
     double *ctS = (double *)(wwS + n), *cyS = ctS + n;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -974,13 +1012,18 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
     for (int i = tid; i < n; i += TS_THREADS) ctS[i] = sa.ct[i];
     for (int i = tid; i < (int)sa.ny; i += TS_THREADS) cyS[i] = sa.cy[i];
     const unsigned ldsBase = (unsigned)(uintptr_t)lds;
-    const i64 laneOff = 2 * (lane & (NP - 1)) + (i64)(lane >> lrows) * map.nin;
-    const i64 pieceStep = (i64)(64 >> lrows) * map.nin;
+    // slot (padi(p) << lrows) + r holds position p of pair r; the forward transform is decimation-in-time, so position p
+    // is element makhoul^-1(bitrev(p)) of the line
     auto dma = [&](int tile, int b) {
-        const double *g = src + ((i64)tile << (lrows + 1)) + laneOff + (i64)(wave * PIPE_ND) * pieceStep;
-        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16) + (unsigned)(wave * PIPE_ND) * 1024u;
+        const double *g0 = src + ((i64)tile << (lrows + 1)) + 2 * (lane & (NP - 1));
+        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16);
 #pragma unroll
-        for (int i = 0; i < PIPE_ND; ++i) glds16(g + i * pieceStep, l0 + (unsigned)i * 1024u);
+        for (int i = 0; i < TS_ND; ++i) {
+            const int c = wave * TS_ND + i;
+            const int q = bitrev(padi(((c << 6) + lane) >> lrows), LG);
+            const int k = (q < (n >> 1)) ? 2 * q : 2 * (n - 1 - q) + 1;
+            glds16(g0 + (i64)k * map.nin, l0 + (unsigned)c * 1024u);
+        }
     };
     int tile = blockIdx.x;
     const int stride = gridDim.x;
@@ -994,24 +1037,7 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
     for (int it = 0; tile < nTiles; tile += stride, ++it) {
         const int b = it & 1;
         double2 *buf = lds + b * BUF;
-        {   // raw [k][pair] -> rows in bit-reversed Makhoul order (the forward transform is decimation-in-time)
-            double vx[2 * TS_IT], vy[2 * TS_IT];
-#pragma unroll
-            for (int u = 0; u < 2 * TS_IT; ++u) {
-                const double2 t = buf[tid + u * TS_THREADS];
-                vx[u] = t.x;
-                vy[u] = t.y;
-            }
-            lds_barrier();
-#pragma unroll
-            for (int u = 0; u < 2 * TS_IT; ++u) {
-                const int e = tid + u * TS_THREADS;
-                const int k = e >> lrows, r = e & (NP - 1);
-                buf[r * RS + padi(bitrev(makhoul(k, n), LG))] = make_double2(vx[u], vy[u]);
-            }
-        }
-        lds_barrier();
-        fft_rows_pipe_dit<LG, lrows, TS_THREADS, RS>(buf, tid, twS);
+        fft_tile_pipe_dit<LG, lrows, TS_THREADS>(buf, tid, twS);
         // spectrum in natural order: DCT post-processing, division, inverse pre-processing on the pair (k, n - k)
         {
             const i64 G0 = sa.line0 + ((i64)tile << (lrows + 1));     // first column of the tile: (y0, x0)
@@ -1020,12 +1046,13 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
 #pragma unroll
             for (int u = 0; u < TS_IT; ++u) {
                 const int bb = tid + u * TS_THREADS;
-                const int rr = bb >> lh;
-                double2 *r = buf + rr * RS;
+                const int rr = bb & (NP - 1);
+                double2 *r = buf + rr;
                 const double ea = cyS[y0 + 2 * rr] + ex, eb = cyS[y0 + 2 * rr + 1] + ex;
-                const int k = (bb & ((1 << lh) - 1)) + 1;          // 1 .. n/2
+                const int k = (bb >> lrows) + 1;                   // 1 .. n/2
                 const int m = n - k;
-                const double2 vk = r[padi(k)], vm = r[padi(m)];
+                const int ik = padi(k) << lrows, im = padi(m) << lrows;
+                const double2 vk = r[ik], vm = r[im];
                 const double2 wk = wwS[k], wm = wwS[m];
                 const double ar = 0.5 * (vk.x + vm.x), ai = 0.5 * (vk.y - vm.y);
                 const double br = 0.5 * (vk.y + vm.y), bi = -0.5 * (vk.x - vm.x);
@@ -1041,16 +1068,16 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
                                                 (wm.x * br + wm.y * bi) / (sa.kscale * lbm));
                 const double gar = 0.5 * (wk.x * xk.x + wm.x * xm.x), gai = 0.5 * (wk.y * xk.x - wm.y * xm.x);
                 const double gbr = 0.5 * (wk.x * xk.y + wm.x * xm.y), gbi = 0.5 * (wk.y * xk.y - wm.y * xm.y);
-                r[padi(k)] = make_double2(gar - gbi, gai + gbr);
+                r[ik] = make_double2(gar - gbi, gai + gbr);
                 if (m != k) {
                     const double har = 0.5 * (wm.x * xm.x + wk.x * xk.x), hai = 0.5 * (wm.y * xm.x - wk.y * xk.x);
                     const double hbr = 0.5 * (wm.x * xm.y + wk.x * xk.y), hbi = 0.5 * (wm.y * xm.y - wk.y * xk.y);
-                    r[padi(m)] = make_double2(har - hbi, hai + hbr);
+                    r[im] = make_double2(har - hbi, hai + hbr);
                 }
             }
             if (tid < NP) {                                        // k = 0: V[0] is its own partner
                 const int rr = tid;
-                double2 *r = buf + rr * RS;
+                double2 *r = buf + rr;
                 double la = (cyS[y0 + 2 * rr] + ex) + ctS[0];
                 double lb2 = (cyS[y0 + 2 * rr + 1] + ex) + ctS[0];
                 if (la == 0.0) la = 1.0;
@@ -1061,16 +1088,16 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
             }
         }
         lds_barrier();
-        fft_rows_pipe<LG, lrows, TS_THREADS, RS>(buf, tid, twS);
+        fft_tile_pipe<LG, lrows, TS_THREADS>(buf, tid, twS);
         {
             const int r0 = tid & (NP - 1), k0 = tid >> lrows;
-            const double2 *rr = buf + r0 * RS;
+            const double2 *rr = buf + r0;
             double *o = dst + ((i64)tile << (lrows + 1)) + 2 * r0 + (i64)k0 * map.nin;
             const i64 ostep = (i64)(TS_THREADS >> lrows) * map.nin;
 #pragma unroll
             for (int u = 0; u < 2 * TS_IT; ++u) {
                 const int k = k0 + u * (TS_THREADS >> lrows);
-                *(double2 *)o = rr[padi(bitrev(makhoul(k, n), LG))];
+                *(double2 *)o = rr[padi(bitrev(makhoul(k, n), LG)) << lrows];
                 o += ostep;
             }
         }
@@ -1599,8 +1626,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 7 && lg <= 10 && map.outerStride == 0) {
         const i64 tileLines = ((i64)2 << TS_LG_CPLX) / n;
         const i64 nxv = sa.ny > 0 ? sa.nplane / sa.ny : 0;
-        const size_t rs = (size_t)n + 1;
-        const size_t ldsPipe = (2 * (rs << (TS_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
+        const size_t ldsPipe = (((size_t)2 << TS_LG_CPLX) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
                                ((size_t)n + (size_t)sa.ny) * sizeof(double);
         const int G = device_cus() * (ldsPipe <= DCT_LDS_MAX / 2 ? 2 : 1);     // two workgroups per CU when they fit
         if (tileLines >= 2 && sa.ny % tileLines == 0 && sa.line0 % tileLines == 0 && map.nLines % tileLines == 0 &&
@@ -1635,8 +1661,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
                 allow_big_lds(k_dct_strided_pipe<0, 9>); allow_big_lds(k_dct_strided_pipe<1, 9>);
                 allow_big_lds(k_dct_strided_pipe<0, 10>); allow_big_lds(k_dct_strided_pipe<1, 10>);
             }
-            const size_t rs = (size_t)n + 1;
-            const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
+            const size_t ldsPipe = (((size_t)2 << PIPE_LG_CPLX) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
 #define SPIPE_LAUNCH(M, LGV)                                                                                         \
     hipLaunchKernelGGL((k_dct_strided_pipe<M, LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, \
                        nTiles, p->tw, p->ww)
