@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_acc_interp(double *__restrict__ x, cons
 int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
                       hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_acc_interp, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, x, xp, aux, n, k, mode,
+    hipLaunchKernelGGL(k_acc_interp, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, xp, aux, n, k, mode,
                        write_aux);
     DS_HIP(hipGetLastError());
     return 0;

@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(256) k_rhs_sigma_fix(double *__restrict__ rhs,
 
 int launch_rhs_sigma_fix(double *rhs, const double *r, double *cvec, i64 n, double factor, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_rhs_sigma_fix, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, rhs, r, cvec, n, factor);
+    hipLaunchKernelGGL(k_rhs_sigma_fix, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, rhs, r, cvec, n, factor);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, i64 n, do
 
 int launch_scale(double *x, i64 n, double mul, double div, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_scale, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, x, n, mul, div,
+    hipLaunchKernelGGL(k_scale, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, n, mul, div,
                        (int)(mul != 1.0));
     DS_HIP(hipGetLastError());
     return 0;

@@ -101,7 +101,7 @@ int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, dou
 
 int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_scale_div, dim3(launch_blocks(n, 256, 1 << 14)), dim3(256), 0, st, x, w, n, sc);
+    hipLaunchKernelGGL(k_scale_div, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, w, n, sc);
     DS_HIP(hipGetLastError());
     return 0;
 }
