@@ -195,14 +195,16 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
                        hipStream_t st);
 int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                      const double *back, double *x, double *qinv, hipStream_t st);
-// up to DS_MAX_WORLD messages copied by ONE launch: message m = count[m] doubles from src[m] (this or a peer device) to
-// dst + dst_off[m] -- the interface exchange of the slabs of one process (P launches instead of P * P copies)
+// up to DS_MAX_WORLD messages copied by ONE launch on the receiving slab's stream: message m = count[m] doubles from
+// src[m] (this or a peer device) to dst[m] -- the exchanges between the slabs of one process (one launch per receiver
+// instead of one event-ordered copy per message)
 struct GatherMsgs {
     const double *src[DS_MAX_WORLD];
-    i64 dst_off[DS_MAX_WORLD], count[DS_MAX_WORLD];
+    double *dst[DS_MAX_WORLD];
+    i64 count[DS_MAX_WORLD];
     int n;
 };
-int launch_gather_msgs(const GatherMsgs &m, double *dst, hipStream_t st);
+int launch_gather_msgs(const GatherMsgs &m, hipStream_t st);
 
 // ---------------- kkt.hip ----------------
 #define KKT_SLICES 64

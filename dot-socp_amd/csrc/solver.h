@@ -60,6 +60,7 @@ struct Slab {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_halo = nullptr;
     hipEvent_t xev[DS_XEV] = {nullptr};   // ordering of cross-slab copies (Solver::xcopy), used round-robin
     hipEvent_t ev_tri = nullptr;          // "this slab's interface message is written" (Solver::tri_exchange, slabs of one process)
+    hipEvent_t ev_msg = nullptr, ev_got = nullptr;   // batched neighbour exchanges: "my messages are written" / "I have pulled mine"
     int xev_next = 0;
     DevRes *res = nullptr;      // plans / tables of `dev`
     double *h_sums = nullptr;   // pinned host copy of this slab's KKT partial sums [S_COUNT]
@@ -249,6 +250,13 @@ struct Solver {
     // from src(slab) to dst(neighbour)
     typedef std::function<double *(Slab &)> Sel;
     int shift(int dir, const Sel &src, const Sel &dst, i64 count);
+    // slabs of one process: the copies of the shift() calls between group_begin() and group_end() (a lone shift() is a
+    // group of one) are collected and pulled by ONE launch per receiving slab (flush_msgs)
+    struct Msg { int from, to; const double *src; double *dst; i64 count; };
+    std::vector<Msg> msgs;
+    int msg_depth = 0;
+    bool msg_batching() const;
+    int flush_msgs();
     int shift_edge_halo(const Sel &base);      // first owned bx / by layers of base(s) -> halo layer of the left slab
     i64 field_len(int field) const;
 

@@ -146,6 +146,8 @@ void Solver::free_slabs() {
         if (s.st) (void)hipStreamSynchronize(s.st);
         for (auto &e : s.xev) if (e) (void)hipEventDestroy(e);
         if (s.ev_tri) (void)hipEventDestroy(s.ev_tri);
+        if (s.ev_msg) (void)hipEventDestroy(s.ev_msg);
+        if (s.ev_got) (void)hipEventDestroy(s.ev_got);
         if (s.st != stream) {        // slab 0 borrows the solver's own streams / events
             if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
             if (s.ev_join) (void)hipEventDestroy(s.ev_join);
@@ -300,6 +302,8 @@ int Solver::alloc_slabs(int first, int count) {
         }
         for (auto &e : s.xev) DS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         DS_HIP(hipEventCreateWithFlags(&s.ev_tri, hipEventDisableTiming));
+        DS_HIP(hipEventCreateWithFlags(&s.ev_msg, hipEventDisableTiming));
+        DS_HIP(hipEventCreateWithFlags(&s.ev_got, hipEventDisableTiming));
         DS_HIP(hipHostMalloc((void **)&s.h_sums, sizeof(double) * S_COUNT));
         s.res = res_for(s.dev);
         if (!s.res) return DOTSOCP_EHIP;
@@ -420,6 +424,14 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
 int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
     if (!multi() || count <= 0) return 0;
     if (!remote()) {
+        if (msg_batching()) {
+            for (size_t i = 0; i + 1 < slabs.size(); ++i) {
+                const int f = (int)((dir > 0) ? i : i + 1), t = (int)((dir > 0) ? i + 1 : i);
+                msgs.push_back(Msg{f, t, src(slabs[f]), dst(slabs[t]), count});
+            }
+            if (msg_depth == 0) DS_CHECK(flush_msgs());       // a lone shift() is a group of one
+            return 0;
+        }
         for (size_t i = 0; i + 1 < slabs.size(); ++i) {
             Slab &from = (dir > 0) ? slabs[i] : slabs[i + 1];
             Slab &to = (dir > 0) ? slabs[i + 1] : slabs[i];
@@ -454,6 +466,8 @@ int Solver::group_begin() {
     if (remote()) {
         DS_NCCL(rccl_api().GroupStart());
         ++open_groups;
+    } else {
+        ++msg_depth;
     }
     return 0;
 }
@@ -462,7 +476,66 @@ int Solver::group_end() {
     if (remote()) {
         --open_groups;
         DS_NCCL(rccl_api().GroupEnd());
+    } else if (--msg_depth == 0) {
+        DS_CHECK(flush_msgs());
     }
+    return 0;
+}
+
+bool Solver::msg_batching() const {
+    const char *e = getenv("DOTSOCP_MSG_BATCH");                  // read per call: the tests switch it inside one process
+    return !(e && atoi(e) == 0);
+}
+
+// The collected copies of a group, as the event-ordered copies of xcopy() would do them but with one set of events and
+// one launch per slab: every sender records "written", every receiver waits for its senders, pulls all its messages
+// with one launch (peer pointers) and records "pulled", every sender waits for its receivers (its buffers are free).
+int Solver::flush_msgs() {
+    if (msgs.empty()) return 0;
+    const size_t P = slabs.size();
+    std::vector<char> sends(P, 0), gets(P, 0);
+    for (const Msg &m : msgs)
+        if (m.count > 0) { sends[m.from] = 1; gets[m.to] = 1; }
+    for (size_t i = 0; i < P; ++i)
+        if (sends[i]) {
+            DS_CHECK(use(slabs[i]));
+            DS_HIP(hipEventRecord(slabs[i].ev_msg, slabs[i].st));
+        }
+    for (size_t t = 0; t < P; ++t) {
+        if (!gets[t]) continue;
+        Slab &to = slabs[t];
+        DS_CHECK(use(to));
+        GatherMsgs g{};
+        g.n = 0;
+        std::vector<char> waited(P, 0);
+        for (const Msg &m : msgs) {
+            if (m.to != (int)t || m.count <= 0) continue;
+            if (!waited[m.from] && slabs[m.from].st != to.st) {
+                DS_HIP(hipStreamWaitEvent(to.st, slabs[m.from].ev_msg, 0));
+                waited[m.from] = 1;
+            }
+            if (g.n == DS_MAX_WORLD) {
+                DS_CHECK(launch_gather_msgs(g, to.st));
+                g.n = 0;
+            }
+            g.src[g.n] = m.src; g.dst[g.n] = m.dst; g.count[g.n] = m.count;
+            ++g.n;
+        }
+        DS_CHECK(launch_gather_msgs(g, to.st));
+        DS_HIP(hipEventRecord(to.ev_got, to.st));
+    }
+    for (size_t f = 0; f < P; ++f) {
+        if (!sends[f]) continue;
+        Slab &from = slabs[f];
+        DS_CHECK(use(from));
+        std::vector<char> waited(P, 0);
+        for (const Msg &m : msgs)
+            if (m.from == (int)f && m.count > 0 && !waited[m.to] && slabs[m.to].st != from.st) {
+                DS_HIP(hipStreamWaitEvent(from.st, slabs[m.to].ev_got, 0));
+                waited[m.to] = 1;
+            }
+    }
+    msgs.clear();
     return 0;
 }
 
@@ -634,16 +707,16 @@ int Solver::tri_exchange(bool back) {
                     const int d = sd.index, q = ss.index;
                     if (!back) {            // slab q's message for owner d
                         m.src[m.n] = ss.tri_send + off(d);
-                        m.dst_off[m.n] = (i64)q * cnt(d);
+                        m.dst[m.n] = sd.tri_recv + (i64)q * cnt(d);
                         m.count[m.n] = cnt(d);
                     } else {                // owner q's answer for slab d
                         m.src[m.n] = ss.tri_bsend + (i64)d * cnt(q);
-                        m.dst_off[m.n] = off(q);
+                        m.dst[m.n] = sd.tri_brecv + off(q);
                         m.count[m.n] = cnt(q);
                     }
                     ++m.n;
                 }
-                DS_CHECK(launch_gather_msgs(m, back ? sd.tri_brecv : sd.tri_recv, sd.st));
+                DS_CHECK(launch_gather_msgs(m, sd.st));
             }
             return 0;
         }

@@ -367,21 +367,21 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
     return 0;
 }
 
-__global__ void __launch_bounds__(256) k_gather_msgs(GatherMsgs a, double *__restrict__ dst) {
+__global__ void __launch_bounds__(256) k_gather_msgs(GatherMsgs a) {
     const int m = blockIdx.y;
     const double *__restrict__ s = a.src[m];
-    double *__restrict__ d = dst + a.dst_off[m];
+    double *__restrict__ d = a.dst[m];
     const i64 c = a.count[m];
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < c; i += (i64)gridDim.x * 256) d[i] = s[i];
 }
 
-int launch_gather_msgs(const GatherMsgs &m, double *dst, hipStream_t st) {
+int launch_gather_msgs(const GatherMsgs &m, hipStream_t st) {
     if (m.n <= 0) return 0;
     i64 cmax = 0;
     for (int i = 0; i < m.n; ++i) cmax = m.count[i] > cmax ? m.count[i] : cmax;
     if (cmax <= 0) return 0;
     const unsigned bx = (unsigned)launch_blocks(cmax, 256, 256);
-    hipLaunchKernelGGL(k_gather_msgs, dim3(bx, (unsigned)m.n), dim3(256), 0, st, m, dst);
+    hipLaunchKernelGGL(k_gather_msgs, dim3(bx, (unsigned)m.n), dim3(256), 0, st, m);
     DS_HIP(hipGetLastError());
     return 0;
 }

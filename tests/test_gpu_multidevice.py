@@ -60,16 +60,19 @@ def test_multi_device_matches_single_slab(method, ngpu, ny, nx, nt, K):
 
 
 @pytest.mark.parametrize("method,ngpu,ny,nx,nt,K", [("inPALM", 3, 40, 36, 48, 30), ("inPALM", 8, 32, 32, 128, 20),
-                                                     ("acc-ADMM", 4, 32, 32, 64, 20)])
+                                                     ("acc-ADMM", 4, 32, 32, 64, 20), ("PALM", 3, 24, 40, 48, 20)])
 def test_interface_messages_by_gather_launch_or_by_copies(method, ngpu, ny, nx, nt, K, monkeypatch):
-    """The interface messages of the partitioned tridiagonal solve travel by one gather launch per receiving slab
-    (default) or by P x P event-ordered copies (DOTSOCP_TRI_GATHER=0): the same doubles end up in the same places, so the
-    two runs must agree to the last bit."""
+    """Between the slabs of one process the interface messages of the partitioned tridiagonal solve and the neighbour
+    messages of a group (halos, tails) are pulled by one launch per receiving slab (default) or travel as event-ordered
+    copies, one per message (DOTSOCP_TRI_GATHER=0, DOTSOCP_MSG_BATCH=0): the same doubles end up in the same places, so
+    the two runs must agree to the last bit."""
     rho0, rho1 = get_example_2d("example1", ny, nx)
     opts = dict(tol=0.0, maxit=K)
     monkeypatch.setenv("DOTSOCP_TRI_GATHER", "0")
+    monkeypatch.setenv("DOTSOCP_MSG_BATCH", "0")
     ref, _, h0, s0, _ = _run(rho0, rho1, nt, opts, method, ngpu=ngpu)
     monkeypatch.setenv("DOTSOCP_TRI_GATHER", "1")
+    monkeypatch.setenv("DOTSOCP_MSG_BATCH", "1")
     got, _, h1, s1, _ = _run(rho0, rho1, nt, opts, method, ngpu=ngpu)
     assert s1 == s0 and np.array_equal(h1["kkt"], h0["kkt"])
     for f in FIELDS:
