@@ -703,12 +703,13 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
 // Pipelined flavour (axis 0, n = 128 .. 1024).  What limits the kernels above is not a unit but the bytes in flight:
 // while a workgroup computes, its tile sits in LDS and nothing of it travels, and the LDS holds two tiles only (the
 // same kernels with the transform skipped run at the copy rate; the transform's time adds in full).  Here ONE
-// persistent workgroup of 512 threads per CU (two waves per SIMD, 256 registers each) walks tiles of 8192 doubles (whole lines, contiguous in memory) through
-// two LDS buffers, and the lines of a tile arrive by LDS-DMA (global_load_lds_dwordx4: no registers, so the loads of
-// tile k+1 and k+2 are in flight during the transform and the stores of tile k):
-//   wait for the DMA of tile k (counted: the stores of tile k-1 and the DMA of tile k+1 are younger and stay in
-//   flight) | raw lines -> paired rows in Makhoul / natural order, in place (all reads, barrier, all writes) |
-//   [inverse pre-processing] | FFT | post-processing + stores | DMA of tile k+2 into the buffer just drained.
+// persistent workgroup of 512 threads per CU (two waves per SIMD, 256 registers each) walks tiles of 8192 doubles
+// (whole lines, contiguous in memory) through two LDS buffers, and the lines of a tile arrive by LDS-DMA
+// (global_load_lds_dwordx4: no registers, so the loads of tile k+1 and k+2 are in flight during the transform and the
+// stores of tile k).  Per tile:
+//   raw lines -> paired rows in Makhoul / natural order, in place (all reads, barrier, all writes) | [inverse
+//   pre-processing] | FFT | post-processing + stores | wait for the DMA of tile k+1 (counted: only the stores just
+//   issued are younger and stay in flight) | barrier | DMA of tile k+2 into the buffer just drained.
 // The twiddle tables live in LDS too: an ordinary global load in the loop would make the compiler wait for
 // everything in flight.  LDS: 2 x 4 x (n + 1) x 16 B + 1.5 n x 16 B = 152 KB at n = 1024.
 // ---------------------------------------------------------------------------------------------
