@@ -255,6 +255,7 @@ struct Solver {
     struct Msg { int from, to; const double *src; double *dst; i64 count; };
     std::vector<Msg> msgs;
     int msg_depth = 0;
+    bool peer_ok = true;      // every pair of devices in use can address each other's memory (alloc_slabs)
     bool msg_batching() const;
     int flush_msgs();
     int shift_edge_halo(const Sel &base);      // first owned bx / by layers of base(s) -> halo layer of the left slab

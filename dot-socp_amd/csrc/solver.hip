@@ -361,8 +361,12 @@ int Solver::alloc_slabs(int first, int count) {
             if (a.dev == b.dev) continue;
             DS_CHECK(use(a));
             hipError_t e = hipDeviceEnablePeerAccess(b.dev, 0);
-            // a refusal is not fatal: hipMemcpyPeerAsync stages through the host without peer access
-            if (e != hipSuccess) (void)hipGetLastError();
+            // a refusal is not fatal: hipMemcpyPeerAsync stages through the host without peer access -- but the launches
+            // that PULL messages through peer pointers (flush_msgs, tri_exchange) must then stay off
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (e != hipErrorPeerAccessAlreadyEnabled) peer_ok = false;
+            }
         }
     return 0;
 }
@@ -484,7 +488,7 @@ int Solver::group_end() {
 
 bool Solver::msg_batching() const {
     const char *e = getenv("DOTSOCP_MSG_BATCH");                  // read per call: the tests switch it inside one process
-    return !(e && atoi(e) == 0);
+    return peer_ok && !(e && atoi(e) == 0);
 }
 
 // The collected copies of a group, as the event-ordered copies of xcopy() would do them but with one set of events and
@@ -696,7 +700,7 @@ int Solver::tri_exchange(bool back) {
         // eight slabs).  "Message written" is one event per slab; the buffers need no event for their reuse: a sender
         // overwrites its message only behind its own next gather, which waits for every receiver of this one.
         const char *ge = getenv("DOTSOCP_TRI_GATHER");            // read per call: the tests switch it inside one process
-        const bool gather = !(ge && atoi(ge) == 0);
+        const bool gather = peer_ok && !(ge && atoi(ge) == 0);
         if (gather) {
             FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_tri, s.st));
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
