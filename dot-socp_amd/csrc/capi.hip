@@ -226,9 +226,18 @@ int dotsocp_oper_poisson(double *res, const double *rhs, dotsocp_i64 ny, dotsocp
     DS_CHECK(table(cx, nx));
     DS_CHECK(table(ct, nt));
     DS_HIP(hipMemcpy(da.p, rhs, sizeof(double) * n, hipMemcpyHostToDevice));
-    DS_CHECK(dctn_dev(da.p, db.p, ny, nx, nt, 0, pl.py, pl.px, pl.pt));
-    DS_CHECK(launch_spectral_divide(db.p, ny, nx, nt, 0, nx, kernelScale, cy.p, cx.p, ct.p, nullptr));
-    DS_CHECK(dctn_dev(db.p, da.p, ny, nx, nt, 1, pl.py, pl.px, pl.pt));
+    if (dct_plan_has_tsolve(pl.pt)) {
+        // the sequence of Solver::poisson_all: y, x forward, the fused t pass (forward, division, inverse), x, y inverse
+        DS_CHECK(launch_dct_axis(pl.py, da.p, db.p, ny, nx, nt, 0, 0, nullptr));
+        DS_CHECK(launch_dct_axis(pl.px, db.p, da.p, ny, nx, nt, 1, 0, nullptr));
+        DS_CHECK(launch_dct_t_solve(pl.pt, da.p, da.p, ny, ny * nx, 0, ny * nx, nt, kernelScale, cy.p, cx.p, ct.p, nullptr));
+        DS_CHECK(launch_dct_axis(pl.px, da.p, db.p, ny, nx, nt, 1, 1, nullptr));
+        DS_CHECK(launch_dct_axis(pl.py, db.p, da.p, ny, nx, nt, 0, 1, nullptr));
+    } else {
+        DS_CHECK(dctn_dev(da.p, db.p, ny, nx, nt, 0, pl.py, pl.px, pl.pt));
+        DS_CHECK(launch_spectral_divide(db.p, ny, nx, nt, 0, nx, kernelScale, cy.p, cx.p, ct.p, nullptr));
+        DS_CHECK(dctn_dev(db.p, da.p, ny, nx, nt, 1, pl.py, pl.px, pl.pt));
+    }
     DS_HIP(hipDeviceSynchronize());
     DS_HIP(hipMemcpy(res, da.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     return 0;

@@ -10,9 +10,7 @@
 // LDS-staged tile (exact, O(n^2) per line; fallback path).
 #include "device_utils.h"
 #include "kernels.h"
-
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>
+#include "pfa.h"
 
 #include <cmath>
 #include <cstdint>
@@ -33,6 +31,7 @@ struct DctPlan {
     double *Ef, *Of;   // Ef[j*ne + k'] = C[2k'][j] (j < njE), Of[j*no + k'] = C[2k'+1][j] (j < h)
     double *Ei, *Oi;   // Ei[k'*njE + j] = C[2k'][j],          Oi[k'*h + j]  = C[2k'+1][j]
     int ne, no, h, njE;
+    PfaPlan *pfa;   // prime-factor transform for the 2^k+1 lengths (pfa.hip); nullptr: dense product
 };
 
 DctPlan *dct_plan_create(i64 n) {
@@ -44,6 +43,7 @@ DctPlan *dct_plan_create(i64 n) {
     p->Cfwd = p->Cinv = nullptr;
     p->Ef = p->Of = p->Ei = p->Oi = nullptr;
     p->ne = p->no = p->h = p->njE = 0;
+    p->pfa = nullptr;
     if (n <= 1) return p;
     const long double PI = 3.141592653589793238462643383279502884L;
     if ((n & (n - 1)) == 0) {
@@ -69,6 +69,13 @@ DctPlan *dct_plan_create(i64 n) {
         (void)hipMemcpy(p->tw, tw.data(), sizeof(double2) * (n / 2), hipMemcpyHostToDevice);
         (void)hipMemcpy(p->ww, ww.data(), sizeof(double2) * n, hipMemcpyHostToDevice);
     } else {
+        if (pfa_supported(n)) {
+            p->pfa = pfa_plan_create(n);
+            if (!p->pfa) {
+                dct_plan_destroy(p);
+                return nullptr;
+            }
+        }
         std::vector<double> cf((size_t)n * n), ci((size_t)n * n);
         for (i64 k = 0; k < n; ++k) {
             long double sc = sqrtl(2.0L / (long double)n);
@@ -121,6 +128,7 @@ void dct_plan_destroy(DctPlan *p) {
     if (p->Of) (void)hipFree(p->Of);
     if (p->Ei) (void)hipFree(p->Ei);
     if (p->Oi) (void)hipFree(p->Oi);
+    pfa_plan_destroy(p->pfa);
     delete p;
 }
 
@@ -1475,76 +1483,6 @@ __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, do
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-// ---------------------------------------------------------------------------------------------
-// Dense lengths through rocBLAS: for a non-power-of-two length (the 2^k+1 grids of the multilevel drivers)
-// the transform along an axis IS a plain matrix product with the n x n DCT matrix -- y: C X (one DGEMM),
-// x: X_t C' for every time layer (strided batch), t: X C' (one DGEMM) -- and a library DGEMM on the fp64
-// matrix cores is the right tool for it (1025 x 1025 x 129: 287 ms per Poisson solve with the LDS-tiled
-// kernel above, ~20 ms as DGEMMs).  librocblas is opened at run time, and only when such a length occurs;
-// without it (or with DOTSOCP_DENSE=kernel) k_dct_dense is used.
-// ---------------------------------------------------------------------------------------------
-struct RocBlas {
-    bool tried = false, ok = false;
-    rocblas_handle handle = nullptr;
-    decltype(&rocblas_create_handle) create = nullptr;
-    decltype(&rocblas_set_stream) set_stream = nullptr;
-    decltype(&rocblas_set_atomics_mode) set_atomics = nullptr;
-    decltype(&rocblas_dgemm) dgemm = nullptr;
-    decltype(&rocblas_dgemm_strided_batched) dgemm_sb = nullptr;
-};
-
-static RocBlas &rocblas_api() {
-    static thread_local RocBlas api;     // one handle per host thread (contexts are single-threaded)
-    if (api.tried) return api;
-    api.tried = true;
-    if (const char *e = getenv("DOTSOCP_DENSE"))
-        if (strcmp(e, "kernel") == 0) return api;
-    void *h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return api;
-    api.create = (decltype(api.create))dlsym(h, "rocblas_create_handle");
-    api.set_stream = (decltype(api.set_stream))dlsym(h, "rocblas_set_stream");
-    api.set_atomics = (decltype(api.set_atomics))dlsym(h, "rocblas_set_atomics_mode");
-    api.dgemm = (decltype(api.dgemm))dlsym(h, "rocblas_dgemm");
-    api.dgemm_sb = (decltype(api.dgemm_sb))dlsym(h, "rocblas_dgemm_strided_batched");
-    if (!api.create || !api.set_stream || !api.dgemm || !api.dgemm_sb) return api;
-    if (api.create(&api.handle) != rocblas_status_success) return api;
-    if (api.set_atomics) (void)api.set_atomics(api.handle, rocblas_atomics_not_allowed);   // run-to-run identical sums
-    api.ok = true;
-    return api;
-}
-
-// out = DCT (inverse: DCT') along `axis` of the [n0][n1][n2] array as DGEMMs; false if rocBLAS is not usable
-static bool dense_axis_rocblas(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis,
-                               int inverse, hipStream_t st) {
-    RocBlas &rb = rocblas_api();
-    if (!rb.ok) return false;
-    const i64 n = p->n;
-    if (n0 * n1 > 0x7fffffff || n1 * n2 > 0x7fffffff || n2 > 0x7fffffff) return false;    // rocblas_int
-    if (rb.set_stream(rb.handle, st) != rocblas_status_success) return false;
-    const double one = 1.0, zero = 0.0;
-    const double *C = p->Cfwd;           // column-major n x n: C(k, j) = Cfwd[j * n + k]
-    rocblas_status rc;
-    if (axis == 0) {
-        // Out (n x L) = C X (forward) / C' X (inverse), L = n1 * n2
-        rc = rb.dgemm(rb.handle, inverse ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none,
-                      (rocblas_int)n, (rocblas_int)(n1 * n2), (rocblas_int)n, &one, C, (rocblas_int)n, src,
-                      (rocblas_int)n, &zero, dst, (rocblas_int)n);
-    } else if (axis == 1) {
-        // per layer t: Out_t (n0 x n) = X_t C' (forward) / X_t C (inverse)
-        rc = rb.dgemm_sb(rb.handle, rocblas_operation_none,
-                         inverse ? rocblas_operation_none : rocblas_operation_transpose, (rocblas_int)n0, (rocblas_int)n,
-                         (rocblas_int)n, &one, src, (rocblas_int)n0, n0 * n1, C, (rocblas_int)n, 0, &zero, dst,
-                         (rocblas_int)n0, n0 * n1, (rocblas_int)n2);
-    } else {
-        // Out (n0 n1 x n) = X C' (forward) / X C (inverse)
-        rc = rb.dgemm(rb.handle, rocblas_operation_none, inverse ? rocblas_operation_none : rocblas_operation_transpose,
-                      (rocblas_int)(n0 * n1), (rocblas_int)n, (rocblas_int)n, &one, src, (rocblas_int)(n0 * n1), C,
-                      (rocblas_int)n, &zero, dst, (rocblas_int)(n0 * n1));
-    }
-    return rc == rocblas_status_success;
-}
-
 #define DCT_LDS_BUDGET (72 * 1024)
 #define DCT_LDS_MAX (160 * 1024)
 
@@ -1585,6 +1523,10 @@ static bool first_on_this_device(unsigned long long &done_mask) {
 }
 
 bool dct_plan_is_pow2(const DctPlan *p) { return p->log2n > 0; }
+bool dct_plan_has_tsolve(const DctPlan *p) {
+    static const bool pfa_on = !(getenv("DOTSOCP_PFA") && atoi(getenv("DOTSOCP_PFA")) == 0);
+    return p->log2n > 0 || (p->pfa && pfa_on);
+}
 
 static int device_cus() {
     static int cus[64] = {0};
@@ -1726,9 +1668,14 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
 
 int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nplane, i64 line0, i64 nl,
                        i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st) {
-    if (p->log2n <= 0 || p->n != nt) {
-        set_error("fused t-axis solve needs a power-of-two nt");
+    if (p->n != nt || !dct_plan_has_tsolve(p)) {
+        set_error("fused t-axis solve needs a power-of-two nt or one of the prime-factor lengths");
         return DOTSOCP_EINVAL;
+    }
+    if (p->log2n <= 0) {
+        if (nl <= 0) return 0;
+        PfaSolveArgs a{kscale, cy, cx, ct, ny, line0, 0};
+        return pfa_launch_strided(p->pfa, src, dst, nl, 1, 0, nl, 0, nl, 2, &a, st);
     }
     LineMap map;
     map.nin = nl;
@@ -1833,13 +1780,20 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             hipLaunchKernelGGL(k_dct_axis0<false>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
                                p->tw, p->ww);
     } else {
+        // DOTSOCP_PFA=0: the dense product also for the lengths that have a prime-factor transform
+        static const bool pfa_on = !(getenv("DOTSOCP_PFA") && atoi(getenv("DOTSOCP_PFA")) == 0);
+        if (p->pfa && pfa_on) {
+            if (axis == 0) return pfa_launch_axis0(p->pfa, src, dst, map.nLines, n0, n0, inverse, st);
+            if (axis == 1) return pfa_launch_strided(p->pfa, src, dst, n0, n2, n0 * n1, n0, n0 * n1, n0, inverse ? 1 : 0, nullptr, st);
+            return pfa_launch_strided(p->pfa, src, dst, n0, n1, n0, n0 * n1, n0, n0 * n1, inverse ? 1 : 0, nullptr, st);
+        }
         if (src == dst) {
             set_error("dense DCT path needs distinct src/dst");
             return DOTSOCP_EINVAL;
         }
-        static const int dense_mode = [] {      // DOTSOCP_DENSE = mfma (default) | rocblas | kernel
+        static const int dense_mode = [] {      // DOTSOCP_DENSE = mfma (default) | kernel
             const char *e = getenv("DOTSOCP_DENSE");
-            return (e && strcmp(e, "rocblas") == 0) ? 1 : ((e && strcmp(e, "kernel") == 0) ? 2 : 0);
+            return (e && strcmp(e, "kernel") == 0) ? 2 : 0;
         }();
         static const bool split = !(getenv("DOTSOCP_MFMA_SPLIT") && atoi(getenv("DOTSOCP_MFMA_SPLIT")) == 0);
         if (dense_mode == 0 && split && p->Ef && map.nLines >= 64) {
@@ -1872,12 +1826,6 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             DS_HIP(hipGetLastError());
             return 0;
         }
-        // the library pays from ~20 GFLOP per pass on (513^2 x 129 and up); below that k_dct_dense needs a few ms at
-        // most and the one-time cost of loading rocBLAS (seconds: it pages in its kernel library) is not worth it
-        static const double min_flop = getenv("DOTSOCP_DENSE_MIN_GFLOP") ? 1e9 * atof(getenv("DOTSOCP_DENSE_MIN_GFLOP")) : 2e10;
-        if (dense_mode == 1 && 2.0 * (double)n * (double)total >= min_flop &&
-            dense_axis_rocblas(p, src, dst, n0, n1, n2, axis, inverse, st))
-            return 0;
         int TL = DENSE_TL;
         while (TL > 1 && (size_t)TL * n * sizeof(double) > 65536) TL >>= 1;
         while (TL > 1 && map.nLines < (i64)TL * 64) TL >>= 1;      // few lines: favour more workgroups

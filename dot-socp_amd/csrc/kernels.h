@@ -252,6 +252,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
 // pencil [nl][nt]: the columns line0 .. line0+nl-1 of the ny*nx = nplane (y, x) columns (y fastest),
 // all nt time nodes; src -> dst (may alias).
 bool dct_plan_is_pow2(const DctPlan *p);
+bool dct_plan_has_tsolve(const DctPlan *p);   // fused forward / divide / inverse pass along t available
 int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nplane, i64 line0, i64 nl,
                        i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st);
 // same pencil, non-power-of-two nt: spectral division only (between two dense DCT passes)

@@ -1084,7 +1084,7 @@ int Solver::begin(const dotsocp_opts *o) {
 // phi = idctn(dctn(rhs) ./ kernel), kernel = D^2 * initialize_FFTkernel  (:96,194); rhs is in w0
 int Solver::poisson_all() {
     const i64 plane = ny * nx;
-    const bool tp2 = dct_plan_is_pow2(devres[0]->pt);
+    const bool tp2 = dct_plan_has_tsolve(devres[0]->pt);
     FOR_SLABS(s) {
         const Grid &g = s.g;
         DS_CHECK(launch_dct_axis(s.res->py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, s.st));

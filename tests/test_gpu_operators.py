@@ -97,6 +97,9 @@ def test_bfd1d_and_conj1d(nt, nx):
 @pytest.mark.parametrize("shape", [(8, 4, 2), (64, 32, 16), (256, 8, 4), (16, 256, 8), (4, 16, 128), (1024, 2, 2),
                                    (5, 6, 7), (33, 17, 9), (129, 3, 2), (16, 1, 8), (129, 1, 33),
                                    (129, 65, 33), (65, 129, 40), (257, 257, 5),
+                                   # prime-factor lengths along every axis, odd line counts, partial tiles
+                                   (1025, 3, 2), (7, 1025, 3), (3, 5, 1025), (513, 11, 3), (20, 513, 2), (17, 9, 5),
+                                   (5, 3, 9), (3, 3, 3), (65, 33, 17), (1025, 1, 1), (1, 513, 1), (1, 1, 129),
                                    (96, 100, 48), (50, 70, 66), (192, 3, 80)])   # even lengths that are no powers of two
 def test_dctn_matches_scipy(shape):
     a = np.asfortranarray(rng.standard_normal(shape))
@@ -106,26 +109,37 @@ def test_dctn_matches_scipy(shape):
     np.testing.assert_allclose(D.mirt_idctn(D.mirt_dctn(a)), a, atol=tol)
 
 
-def test_dctn_dense_lengths_through_dgemm():
-    """DOTSOCP_DENSE=rocblas: non-power-of-two lengths above a work threshold as library DGEMMs (y: C X, x: strided
-    batch X_t C', t: X C') instead of the hand-written fp64-MFMA kernel that is the default (k_dct_mfma, exercised
-    by the non-power-of-two shapes of the tests around this one).  Mode and threshold are read once per process,
-    hence the subprocess."""
+def test_prime_factor_dct_against_the_dense_product():
+    """The 2^k+1 lengths (1025 = 25 x 41, 513 = 27 x 19, 129 = 3 x 43, 65, 33, 17, 9, 5, 3) take the prime-factor
+    transform of csrc/pfa.hip; DOTSOCP_PFA=0 (read once per process, hence the subprocess) sends them through the dense
+    DCT-matrix product instead.  Two different algorithms for the same transform: results agree to rounding, for the
+    transforms along every axis and for the Poisson solve (fused t-axis pass against three separate ones)."""
     import os
     import subprocess
     import sys
+    import tempfile
     code = (
-        "import numpy as np, scipy.fft as sf, dotsocp_amd as D\n"
-        "rng = np.random.default_rng(7)\n"
-        "for shape in [(129, 65, 33), (65, 129, 40), (257, 130, 9)]:\n"
+        "import sys, numpy as np, dotsocp_amd as D\n"
+        "rng = np.random.default_rng(12)\n"
+        "out = {}\n"
+        "for i, shape in enumerate([(1025, 6, 3), (10, 1025, 3), (513, 9, 17), (18, 513, 5), (33, 65, 129), (129, 17, 9), (5, 3, 1025)]):\n"
         "    a = np.asfortranarray(rng.standard_normal(shape))\n"
-        "    np.testing.assert_allclose(D.mirt_dctn(a), sf.dctn(a, norm='ortho'), atol=2e-12)\n"
-        "    np.testing.assert_allclose(D.mirt_idctn(a), sf.idctn(a, norm='ortho'), atol=2e-12)\n"
-        "print('ok')\n")
-    env = dict(os.environ, DOTSOCP_DENSE="rocblas", DOTSOCP_DENSE_MIN_GFLOP="0.001")
+        "    out['f%d' % i] = D.mirt_dctn(a); out['i%d' % i] = D.mirt_idctn(a)\n"
+        "    out['p%d' % i] = D.oper_poisson3dim(0.37 ** 2, a)\n"
+        "np.savez(sys.argv[1], **out)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for flag in ("0", "1"):
+            path = os.path.join(tmp, f"pfa{flag}.npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DOTSOCP_PFA=flag), cwd=root,
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-2000:]
+            with np.load(path) as z:
+                res[flag] = {k: z[k].copy() for k in z.files}
+    for k in res["0"]:
+        ref = res["0"][k]
+        np.testing.assert_allclose(res["1"][k], ref, rtol=0, atol=2e-13 * max(1.0, np.abs(ref).max()) * np.sqrt(ref.size), err_msg=k)
 
 
 @pytest.mark.parametrize("shape", [(1024, 1024, 16), (512, 2048, 8), (256, 4096, 8), (128, 8192, 8), (1024, 1023, 9),
@@ -142,7 +156,8 @@ def test_dctn_many_lines(shape):
 
 
 @pytest.mark.parametrize("ny,nx,nt", [(16, 16, 8), (64, 32, 16), (9, 5, 3), (33, 33, 17), (128, 1, 32), (65, 65, 33),
-                                      (129, 64, 17),
+                                      (129, 64, 17), (129, 129, 33), (1025, 1, 33), (513, 40, 129), (40, 1025, 9),
+                                      (64, 64, 65), (7, 3, 513),
                                       # large enough for the pipelined kernels (fused t-axis solve of length 128 .. 1024)
                                       (256, 128, 128), (128, 512, 256), (64, 512, 512), (32, 1024, 1024),
                                       (256, 160, 128), (64, 1000, 128)])        # tile counts that leave a remainder
