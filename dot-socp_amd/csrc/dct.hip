@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace dotsocp {
@@ -1513,14 +1514,24 @@ static void allow_big_lds(K kernel) {
 
 // Function attributes belong to the (function, device) pair: a process that drives several GPUs (dotsocp_create_multi)
 // has to raise the dynamic-LDS limit once on EVERY device it launches on.  true = not done yet on the current device.
-static bool first_on_this_device(unsigned long long &done_mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    const unsigned long long bit = 1ull << dev;
-    if (done_mask & bit) return false;
-    done_mask |= bit;
-    return true;
-}
+static std::mutex attr_mutex;
+struct DeviceOnce {
+    // `if (DeviceOnce once(mask); once) { raise the attributes }`: the lock is held while they are raised and the device's
+    // bit is set only afterwards, so a second host thread can neither skip the block early nor launch in between
+    std::unique_lock<std::mutex> lock;
+    unsigned long long *mask;
+    unsigned long long bit = 0;
+    bool first = true;
+    explicit DeviceOnce(unsigned long long &m) : lock(attr_mutex), mask(&m) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            bit = 1ull << dev;
+            first = !(m & bit);
+        }
+    }
+    ~DeviceOnce() { if (first && bit) *mask |= bit; }
+    explicit operator bool() const { return first; }
+};
 
 bool dct_plan_is_pow2(const DctPlan *p) { return p->log2n > 0; }
 bool dct_plan_has_tsolve(const DctPlan *p) {
@@ -1577,7 +1588,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
             map.nLines / tileLines < (1ll << 30)) {
             const int nTiles = (int)(map.nLines / tileLines);
             static unsigned long long done_tp = 0;
-            if (first_on_this_device(done_tp)) {
+            if (DeviceOnce once_(done_tp); once_) {
                 allow_big_lds(k_dct_tsolve_pipe<7>); allow_big_lds(k_dct_tsolve_pipe<8>);
                 allow_big_lds(k_dct_tsolve_pipe<9>); allow_big_lds(k_dct_tsolve_pipe<10>);
             }
@@ -1598,7 +1609,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
             map.nLines / tileLines < (1ll << 30)) {
             const int nTiles = (int)(map.nLines / tileLines);
             static unsigned long long done_sp = 0;
-            if (first_on_this_device(done_sp)) {
+            if (DeviceOnce once_(done_sp); once_) {
                 allow_big_lds(k_dct_strided_pipe<0, 7>); allow_big_lds(k_dct_strided_pipe<1, 7>);
                 allow_big_lds(k_dct_strided_pipe<0, 8>); allow_big_lds(k_dct_strided_pipe<1, 8>);
                 allow_big_lds(k_dct_strided_pipe<0, 9>); allow_big_lds(k_dct_strided_pipe<1, 9>);
@@ -1622,7 +1633,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     }
     if (dct_wg_enabled() && vec && mode != 2 && ((i64)n << lp) >= 2 * DCT_WG_THREADS) {
         static unsigned long long done_wg = 0;
-        if (first_on_this_device(done_wg)) {
+        if (DeviceOnce once_(done_wg); once_) {
             allow_big_lds(k_dct_strided_wg<0, 512>); allow_big_lds(k_dct_strided_wg<1, 512>);
             allow_big_lds(k_dct_strided_wg<0, 1024>); allow_big_lds(k_dct_strided_wg<1, 1024>);
         }
@@ -1654,7 +1665,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
 #define LAUNCH_STRIDED(M, V)                                                                                   \
     do {                                                                                                       \
         static unsigned long long done = 0;                                                                    \
-        if (first_on_this_device(done)) allow_big_lds(k_dct_strided<M, V>);                                    \
+        if (DeviceOnce once_(done); once_) allow_big_lds(k_dct_strided<M, V>);                                    \
         hipLaunchKernelGGL((k_dct_strided<M, V>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, lg, \
                            lp, sa, p->tw, p->ww);                                                              \
     } while (0)
@@ -1725,7 +1736,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         const i64 linesPerBlock = (i64)(2 * DCT_WAVES) << lrw;
         const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
         static unsigned long long done = 0;
-        if (first_on_this_device(done)) {
+        if (DeviceOnce once_(done); once_) {
             allow_big_lds(k_dct_axis0<false>); allow_big_lds(k_dct_axis0<true>);
             allow_big_lds(k_dct_axis0_wg<false>); allow_big_lds(k_dct_axis0_wg<true>);
         }
@@ -1737,7 +1748,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             const int ncu = device_cus();
             if (nTiles >= 2 * (i64)ncu && nTiles < (1ll << 30)) {
                 static unsigned long long done_pipe = 0;
-                if (first_on_this_device(done_pipe)) {
+                if (DeviceOnce once_(done_pipe); once_) {
                     allow_big_lds(k_dct_axis0_pipe<false, 7>); allow_big_lds(k_dct_axis0_pipe<true, 7>);
                     allow_big_lds(k_dct_axis0_pipe<false, 8>); allow_big_lds(k_dct_axis0_pipe<true, 8>);
                     allow_big_lds(k_dct_axis0_pipe<false, 9>); allow_big_lds(k_dct_axis0_pipe<true, 9>);

@@ -51,8 +51,14 @@ bool stream_stress_enabled() {
 }
 
 void stream_stress(hipStream_t st) {
-    static unsigned long long state = 0x9e3779b97f4a7c15ull;
-    state ^= state << 13; state ^= state >> 7; state ^= state << 17;       // xorshift: reproducible sequence per process
+    static std::mutex mu;                                                  // contexts may be driven from several host threads
+    static unsigned long long shared_state = 0x9e3779b97f4a7c15ull;
+    unsigned long long state;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        shared_state ^= shared_state << 13; shared_state ^= shared_state >> 7; shared_state ^= shared_state << 17;   // xorshift
+        state = shared_state;
+    }
     if ((state & 3) == 0) return;                                          // a quarter of the calls add nothing
     const long long ticks = (long long)((state >> 8) % 30000);             // up to 300 us at 100 MHz
     hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, st, ticks);

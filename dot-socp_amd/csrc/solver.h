@@ -256,6 +256,8 @@ struct Solver {
     std::vector<Msg> msgs;
     int msg_depth = 0;
     bool peer_ok = true;      // every pair of devices in use can address each other's memory (alloc_slabs)
+    bool cross_device = false;   // some pair of this process's slabs lives on different devices (alloc_slabs)
+    bool pull_default(const char *env_var) const;
     bool msg_batching() const;
     int flush_msgs();
     int shift_edge_halo(const Sel &base);      // first owned bx / by layers of base(s) -> halo layer of the left slab

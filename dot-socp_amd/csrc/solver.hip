@@ -101,8 +101,14 @@ int Solver::xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, doub
     DS_HIP(hipEventRecord(a, from.st));
     DS_CHECK(use(to));
     DS_HIP(hipStreamWaitEvent(to.st, a, 0));
-    // different devices: peer access was enabled in both directions when the slabs were placed (alloc_slabs)
-    DS_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+    if (from.dev == to.dev || peer_ok) {
+        // different devices: peer access was enabled in both directions when the slabs were placed (alloc_slabs)
+        DS_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+    } else {
+        // peer access refused: row by row through hipMemcpyPeerAsync, which stages through the host by itself
+        for (size_t r = 0; r < height; ++r)
+            DS_HIP(hipMemcpyPeerAsync((char *)dst + r * dpitch, to.dev, (const char *)src + r * spitch, from.dev, width, to.st));
+    }
     DS_HIP(hipEventRecord(b, to.st));
     DS_CHECK(use(from));
     DS_HIP(hipStreamWaitEvent(from.st, b, 0));
@@ -282,6 +288,8 @@ int Solver::ensure_alloc() {
 
 int Solver::alloc_slabs(int first, int count) {
     free_slabs();
+    peer_ok = true;
+    cross_device = false;
     slabs.resize(count);
     const i64 plane = ny * nx;
     for (int r = 0; r < count; ++r) {
@@ -359,6 +367,7 @@ int Solver::alloc_slabs(int first, int count) {
     for (auto &a : slabs)
         for (auto &b : slabs) {
             if (a.dev == b.dev) continue;
+            cross_device = true;
             DS_CHECK(use(a));
             hipError_t e = hipDeviceEnablePeerAccess(b.dev, 0);
             // a refusal is not fatal: hipMemcpyPeerAsync stages through the host without peer access -- but the launches
@@ -486,10 +495,19 @@ int Solver::group_end() {
     return 0;
 }
 
-bool Solver::msg_batching() const {
-    const char *e = getenv("DOTSOCP_MSG_BATCH");                  // read per call: the tests switch it inside one process
-    return peer_ok && !(e && atoi(e) == 0);
+// Pull launches (a kernel on the receiver's device reading the sender's memory through a peer pointer): the default
+// between slabs of ONE device.  Between different devices the event-ordered hipMemcpyPeerAsync copies are the default
+// and the pull launches are opt-in (DOTSOCP_MSG_BATCH=1 / DOTSOCP_TRI_GATHER=1): whether the reading device's L2
+// returns fresh lines of another device's coarse-grained memory behind nothing but an event wait has never been
+// observed on two devices (the build's boxes have one).
+bool Solver::pull_default(const char *var) const {
+    const char *e = getenv(var);                                  // read per call: the tests switch it inside one process
+    if (!peer_ok) return false;
+    if (e) return atoi(e) != 0;
+    return !cross_device;
 }
+
+bool Solver::msg_batching() const { return pull_default("DOTSOCP_MSG_BATCH"); }
 
 // The collected copies of a group, as the event-ordered copies of xcopy() would do them but with one set of events and
 // one launch per slab: every sender records "written", every receiver waits for its senders, pulls all its messages
@@ -699,8 +717,7 @@ int Solver::tri_exchange(bool back) {
         // P * P stream waits instead of P * P event-ordered copies, whose host cost grew to 2.8 ms per iteration at
         // eight slabs).  "Message written" is one event per slab; the buffers need no event for their reuse: a sender
         // overwrites its message only behind its own next gather, which waits for every receiver of this one.
-        const char *ge = getenv("DOTSOCP_TRI_GATHER");            // read per call: the tests switch it inside one process
-        const bool gather = peer_ok && !(ge && atoi(ge) == 0);
+        const bool gather = pull_default("DOTSOCP_TRI_GATHER");
         if (gather) {
             FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_tri, s.st));
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)

@@ -89,7 +89,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     const int device = (int)opt(O, "device", 0);
     /* opts.ngpu > 1: the time axis is cut into that many slabs, slab r on device (device + r) mod #devices of THIS
      * process (dotsocp_create_multi: streams per slab, peer copies between neighbours) -- MATLAB stays one process */
-    const int ngpu = (int)opt(O, "ngpu", 1);
+    int ngpu = (int)opt(O, "ngpu", 1);
 
     /* every array is checked against the grid BEFORE the context exists (nothing to release on these errors) */
     static const char *names[] = {"phi", "q", "alpha", "z", "beta", "c"};
@@ -98,6 +98,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     for (int i = 0; i < 6; ++i) in[i] = sized(need(S, names[i]), &p, fields[i], names[i]);
     in[6] = p.weighted ? sized(wf, &p, DOTSOCP_F_WEIGHT, "weight") : NULL;
     if (ngpu < 1) mexErrMsgIdAndTxt(ID, "opts.ngpu must be >= 1");
+    /* the multilevel driver hands the same opts to every level (solver_dotsocp2d.m:208): a coarse level with fewer than
+     * 2 * ngpu time nodes runs on fewer slabs (at least two time nodes per slab), like dotsocp_level_mex does */
+    if (ngpu > p.nt / 2) ngpu = (int)(p.nt / 2);
+    if (ngpu < 1) ngpu = 1;
 
     dotsocp_ctx *ctx = dotsocp_create_multi(&p, device, ngpu);
     if (!ctx) mexErrMsgIdAndTxt(ID, "%s", dotsocp_last_error());

@@ -13,164 +13,195 @@ from .driver import InitialScaling, default_opts, make_state, recoverOrgVar
 from .model import initialize
 
 
-def _pairmean(a, axis):
-    """movmean(a, 2, axis, 'Endpoints', 'discard')  (interpolate.m:35-37)"""
-    s0 = [slice(None)] * a.ndim
-    s1 = [slice(None)] * a.ndim
-    s0[axis], s1[axis] = slice(0, -1), slice(1, None)
-    return (a[tuple(s0)] + a[tuple(s1)]) / 2.0
+# ---------------------------------------------------------------------------------------------------------------
+# The restriction / prolongation operators below are written STRAIGHT from the .m files, statement by statement and
+# with the reference's own 1-based index vectors (explicit loops, sparse kron products) -- deliberately NOT the
+# vectorised form of dot-socp_amd/multilevel.py, so that tests/test_multilevel.py compares two implementations.
+# ---------------------------------------------------------------------------------------------------------------
+import scipy.sparse as sp
 
 
 def downSample_phi(v):
-    """socp/dot2d/utils/downSample_phi.m:5-34 (full weighting; the original uses the row index range for
-    both dimensions and has `v(2,1)` twice in the (1,1) corner -- restated literally) and
+    """socp/dot2d/utils/downSample_phi.m:5-34, element by element in the reference's 1-based indices (the original
+    uses `ind = 3:2:(Mx-1)` for rows AND columns and has `v(2,1)` twice in the (1,1) corner -- kept), and
     socp/dot1d/utils/downSample_phi.m:4-12."""
     v = np.asarray(v, dtype=np.float64)
     if v.ndim == 1:
-        n = v.size - 1
-        nc = n // 2
-        out = np.zeros(nc + 1)
-        ind = np.arange(2, n - 1, 2)                      # MATLAB 3:2:len-1 (0-based)
-        out[1:nc] = 0.5 * v[ind] + 0.25 * (v[ind - 1] + v[ind + 1])
-        out[0] = (2 / 3) * v[0] + (1 / 3) * v[1]
-        out[-1] = (1 / 3) * v[-2] + (2 / 3) * v[-1]
-        return out
-    Mx, My = v.shape[0] - 1, v.shape[1] - 1
+        ln = v.size - 1                                   # dot1d downSample_phi.m:4
+        lenc = ln // 2
+        phic = np.zeros(lenc + 1)
+        V = lambda i: v[i - 1]                            # 1-based access  # noqa: E731
+        for c, i in enumerate(range(3, ln - 1 + 1, 2)):   # ind = 3:2:len-1 -> phic(2:lenc)
+            phic[1 + c] = 0.5 * V(i) + 0.25 * (V(i - 1) + V(i + 1))
+        phic[0] = (2 / 3) * V(1) + (1 / 3) * V(2)
+        phic[lenc] = (1 / 3) * V(ln) + (2 / 3) * V(ln + 1)
+        return phic
+    Mx, My = v.shape[0] - 1, v.shape[1] - 1               # :5
     Mxc, Myc = Mx // 2, My // 2
     vc = np.zeros((Mxc + 1, Myc + 1))
-    ind = np.arange(2, Mx - 1, 2)                         # 3:2:(Mx-1), used for rows AND columns
-    I, J = np.ix_(ind, ind)
-    vc[1:Mxc, 1:Myc] = (4 * v[I, J] + 2 * (v[I - 1, J] + v[I + 1, J] + v[I, J - 1] + v[I, J + 1])
-                        + (v[I - 1, J - 1] + v[I - 1, J + 1] + v[I + 1, J - 1] + v[I + 1, J + 1])) / 16
-    vc[0, 1:Myc] = (4 * v[0, ind] + 2 * (v[1, ind] + v[0, ind - 1] + v[0, ind + 1]) + (v[1, ind - 1] + v[1, ind + 1])) / 12
-    vc[Mxc, 1:Myc] = (4 * v[Mx, ind] + 2 * (v[Mx - 1, ind] + v[Mx, ind - 1] + v[Mx, ind + 1])
-                      + (v[Mx - 1, ind - 1] + v[Mx - 1, ind + 1])) / 12
-    vc[1:Mxc, 0] = (4 * v[ind, 0] + 2 * (v[ind - 1, 0] + v[ind + 1, 0] + v[ind, 1]) + (v[ind - 1, 1] + v[ind + 1, 1])) / 12
-    vc[1:Mxc, Myc] = (4 * v[ind, My] + 2 * (v[ind - 1, My] + v[ind + 1, My] + v[ind, My - 1])
-                      + (v[ind - 1, My - 1] + v[ind + 1, My - 1])) / 12
-    vc[0, 0] = (4 * v[0, 0] + 2 * (v[1, 0] + v[0, 1]) + v[1, 0]) / 9
-    vc[0, Myc] = (4 * v[0, My] + 2 * (v[1, My] + v[0, My - 1]) + v[1, My - 1]) / 9
-    vc[Mxc, 0] = (4 * v[Mx, 0] + 2 * (v[Mx - 1, 0] + v[Mx, 1]) + v[Mx - 1, 1]) / 9
-    vc[Mxc, Myc] = (4 * v[Mx, My] + 2 * (v[Mx - 1, My] + v[Mx, My - 1]) + v[Mx - 1, My - 1]) / 9
+    V = lambda i, j: v[i - 1, j - 1]                      # noqa: E731
+    ind = list(range(3, Mx - 1 + 1, 2))                   # :9  (one vector for both dimensions)
+    if len(ind) != Myc - 1:
+        # vc(2:Mxc,2:Myc) = f(v(ind,ind)): MATLAB raises a dimension mismatch unless the array is square
+        raise ValueError("downSample_phi: the reference indexes both axes with the row range (square arrays only)")
+    for a, i in enumerate(ind):                           # :11-15 -> vc(2:Mxc, 2:Myc)
+        for b, j in enumerate(ind):
+            vc[1 + a, 1 + b] = (4 * V(i, j) + 2 * (V(i - 1, j) + V(i + 1, j) + V(i, j - 1) + V(i, j + 1))
+                                + (V(i - 1, j - 1) + V(i - 1, j + 1) + V(i + 1, j - 1) + V(i + 1, j + 1))) / 16
+    for b, j in enumerate(ind):                           # :17-22 first / last row
+        vc[0, 1 + b] = (4 * V(1, j) + 2 * (V(2, j) + V(1, j - 1) + V(1, j + 1)) + (V(2, j - 1) + V(2, j + 1))) / 12
+        vc[Mxc, 1 + b] = (4 * V(Mx + 1, j) + 2 * (V(Mx, j) + V(Mx + 1, j - 1) + V(Mx + 1, j + 1))
+                          + (V(Mx, j - 1) + V(Mx, j + 1))) / 12
+    for a, i in enumerate(ind):                           # :23-28 first / last column
+        vc[1 + a, 0] = (4 * V(i, 1) + 2 * (V(i - 1, 1) + V(i + 1, 1) + V(i, 2)) + (V(i - 1, 2) + V(i + 1, 2))) / 12
+        vc[1 + a, Myc] = (4 * V(i, My + 1) + 2 * (V(i - 1, My + 1) + V(i + 1, My + 1) + V(i, My))
+                          + (V(i - 1, My) + V(i + 1, My))) / 12
+    vc[0, 0] = (4 * V(1, 1) + 2 * (V(2, 1) + V(1, 2)) + V(2, 1)) / 9                       # :30
+    vc[0, Myc] = (4 * V(1, My + 1) + 2 * (V(2, My + 1) + V(1, My)) + V(2, My)) / 9         # :31
+    vc[Mxc, 0] = (4 * V(Mx + 1, 1) + 2 * (V(Mx, 1) + V(Mx + 1, 2)) + V(Mx, 2)) / 9         # :32
+    vc[Mxc, Myc] = (4 * V(Mx + 1, My + 1) + 2 * (V(Mx, My + 1) + V(Mx + 1, My)) + V(Mx, My)) / 9   # :33-34
     return vc
 
 
+def _movmean2(f, d):
+    """movmean(f, 2, d, 'Endpoints', 'discard')  (interpolate.m:17-19): means of neighbouring pairs along dim d"""
+    n = f.shape[d]
+    out_shape = list(f.shape)
+    out_shape[d] = n - 1
+    out = np.empty(out_shape)
+    for i in range(n - 1):
+        lo = [slice(None)] * f.ndim
+        hi = [slice(None)] * f.ndim
+        dst = [slice(None)] * f.ndim
+        lo[d], hi[d], dst[d] = i, i + 1, i
+        out[tuple(dst)] = (f[tuple(lo)] + f[tuple(hi)]) / 2.0
+    return out
+
+
 def interpolate_phi(phi, dims):
-    """interpolate.m:46-71 (2-D: trilinear) / dot1d interpolate.m:41-61"""
-    f = np.asarray(phi).reshape(dims, order="F")
-    for ax in range(f.ndim):
-        n = f.shape[ax]
-        shp = list(f.shape)
-        shp[ax] = 2 * (n - 1) + 1
-        g = np.zeros(shp)
-        s_odd = [slice(None)] * f.ndim
-        s_even = [slice(None)] * f.ndim
-        s_odd[ax], s_even[ax] = slice(0, None, 2), slice(1, None, 2)
-        g[tuple(s_odd)] = f
-        g[tuple(s_even)] = _pairmean(f, ax)
-        f = g
-    return f.ravel(order="F")
+    """interpolate.m:46-71 (2-D: y, then x, then t linear, on the odd / even index vectors of the reference) and
+    socp/dot1d/utils/interpolate.m (x, then t)."""
+    if len(dims) == 3:
+        ny, nx, nt = dims
+        nyR, nxR, ntR = 2 * (ny - 1) + 1, 2 * (nx - 1) + 1, 2 * (nt - 1) + 1
+        oddY, evenY = np.arange(0, nyR, 2), np.arange(1, nyR - 1, 2)        # 1:2:nyR, 2:2:nyR-1 (0-based here)
+        oddX, evenX = np.arange(0, nxR, 2), np.arange(1, nxR - 1, 2)
+        oddT, evenT = np.arange(0, ntR, 2), np.arange(1, ntR - 1, 2)
+        phiR = np.zeros((nyR, nxR, ntR))
+        phiR[np.ix_(oddY, oddX, oddT)] = np.asarray(phi).reshape((ny, nx, nt), order="F")
+        phiR[np.ix_(evenY, oddX, oddT)] = _movmean2(phiR[np.ix_(oddY, oddX, oddT)], 0)
+        phiR[np.ix_(np.arange(nyR), evenX, oddT)] = _movmean2(phiR[np.ix_(np.arange(nyR), oddX, oddT)], 1)
+        phiR[:, :, evenT] = _movmean2(phiR[:, :, oddT], 2)
+        return phiR.reshape(-1, order="F")
+    nx, nt = dims
+    nxR, ntR = 2 * (nx - 1) + 1, 2 * (nt - 1) + 1
+    oddX, evenX = np.arange(0, nxR, 2), np.arange(1, nxR - 1, 2)
+    oddT, evenT = np.arange(0, ntR, 2), np.arange(1, ntR - 1, 2)
+    phiR = np.zeros((nxR, ntR))
+    phiR[np.ix_(oddX, oddT)] = np.asarray(phi).reshape((nx, nt), order="F")
+    phiR[np.ix_(evenX, oddT)] = _movmean2(phiR[np.ix_(oddX, oddT)], 0)
+    phiR[:, evenT] = _movmean2(phiR[:, oddT], 1)
+    return phiR.reshape(-1, order="F")
+
+
+def _interpolate_tStagger(f):
+    """interpolate.m:22-44: nearest in t (each coarse cell fills fine cells 2t-1 and 2t), linear in y, then in x"""
+    if f.ndim == 3:
+        ny, nx, nt = f.shape
+        nyR, nxR, ntR = 2 * (ny - 1) + 1, 2 * (nx - 1) + 1, 2 * nt
+        oddY, evenY = np.arange(0, nyR, 2), np.arange(1, nyR - 1, 2)
+        oddX, evenX = np.arange(0, nxR, 2), np.arange(1, nxR - 1, 2)
+        oddT, evenT = np.arange(0, ntR - 1, 2), np.arange(1, ntR, 2)
+        fR = np.zeros((nyR, nxR, ntR))
+        fR[np.ix_(oddY, oddX, oddT)] = f
+        fR[np.ix_(oddY, oddX, evenT)] = f
+        fR[np.ix_(evenY, oddX, np.arange(ntR))] = _movmean2(fR[np.ix_(oddY, oddX, np.arange(ntR))], 0)
+        fR[:, evenX, :] = _movmean2(fR[:, oddX, :], 1)
+        return fR
+    nx, nt = f.shape
+    nxR, ntR = 2 * (nx - 1) + 1, 2 * nt
+    oddX, evenX = np.arange(0, nxR, 2), np.arange(1, nxR - 1, 2)
+    oddT, evenT = np.arange(0, ntR - 1, 2), np.arange(1, ntR, 2)
+    fR = np.zeros((nxR, ntR))
+    fR[np.ix_(oddX, oddT)] = f
+    fR[np.ix_(oddX, evenT)] = f
+    fR[evenX, :] = _movmean2(fR[oddX, :], 0)
+    return fR
 
 
 def interpolate_z(z, dims):
-    """interpolate.m:20-44,73-84: per cone column, nearest in t (each coarse cell -> two fine cells),
-    linear in the space axes.  dims = (ny, nx, nt) or (nx, nt) of the COARSE grid."""
+    """interpolate.m:73-84: column by column through interpolate_tStagger.  dims = (ny, nx, nt) or (nx, nt) of the
+    COARSE grid."""
     K = z.shape[1]
-    sp = dims[:-1]
+    sp_dims = tuple(dims[:-1])
     ntc = dims[-1] - 1
-    cols = []
-    for j in range(K):
-        f = z[:, j].reshape(tuple(sp) + (ntc,), order="F")
-        f = np.repeat(f, 2, axis=-1)                       # fR(.., oddT) = fR(.., evenT) = f
-        for ax in range(len(sp)):
-            n = f.shape[ax]
-            shp = list(f.shape)
-            shp[ax] = 2 * (n - 1) + 1
-            g = np.zeros(shp)
-            s_odd = [slice(None)] * f.ndim
-            s_even = [slice(None)] * f.ndim
-            s_odd[ax], s_even[ax] = slice(0, None, 2), slice(1, None, 2)
-            g[tuple(s_odd)] = f
-            g[tuple(s_even)] = _pairmean(f, ax)
-            f = g
-        cols.append(f.ravel(order="F"))
-    return np.asfortranarray(np.stack(cols, axis=1))
+    first = _interpolate_tStagger(z[:, 0].reshape(sp_dims + (ntc,), order="F"))
+    zR = np.zeros((first.size, K), order="F")
+    zR[:, 0] = first.reshape(-1, order="F")
+    for j in range(1, K):
+        zR[:, j] = _interpolate_tStagger(z[:, j].reshape(sp_dims + (ntc,), order="F")).reshape(-1, order="F")
+    return zR
 
 
-def _restrict_linear(nC):
-    """(P ./ sum(P,1))' for gene_prolongMat1dim_linear(nC)  (downSample_barrier.m:26-32,10-12)"""
+def _gene_prolongMat1dim_linear(nC):
+    """downSample_q.m:25-31 (triplets iVec / jVec / vVec, 1-based in the reference)"""
     nR = 2 * (nC - 1) + 1
-    P = np.zeros((nR, nC))
-    P[np.arange(0, nR, 2), np.arange(nC)] = 1.0
-    P[np.arange(1, nR - 1, 2), np.arange(nC - 1)] = 0.5
-    P[np.arange(1, nR - 1, 2), np.arange(1, nC)] = 0.5
-    return (P / P.sum(axis=0)).T
+    iVec = list(range(1, nR + 1, 2)) + list(range(2, nR, 2)) * 2
+    jVec = list(range(1, nC + 1)) + list(range(1, nC)) + list(range(2, nC + 1))
+    vVec = [1.0] * nC + [0.5] * (2 * (nC - 1))
+    return sp.csc_matrix((vVec, (np.array(iVec) - 1, np.array(jVec) - 1)), shape=(nR, nC))
 
 
-def _restrict_nearest(nC):
+def _gene_prolongMat1dim_nearest(nC):
+    """downSample_q.m:33-39"""
     nR = 2 * nC
-    P = np.zeros((nR, nC))
-    P[np.arange(0, nR, 2), np.arange(nC)] = 1.0
-    P[np.arange(1, nR, 2), np.arange(nC)] = 1.0
-    return (P / P.sum(axis=0)).T
+    iVec = list(range(1, nR + 1, 2)) + list(range(2, nR + 1, 2))
+    jVec = list(range(1, nC + 1)) * 2
+    return sp.csc_matrix(([1.0] * (2 * nC), (np.array(iVec) - 1, np.array(jVec) - 1)), shape=(nR, nC))
 
 
-def _apply3(v, shape, Ry, Rx, Rt):
-    """kron(kron(Rt, Rx), Ry) * v for v stored y fastest, then x, then t"""
-    a = v.reshape(shape, order="F")
-    a = np.tensordot(Ry, a, axes=(1, 0))
-    a = np.moveaxis(np.tensordot(Rx, a, axes=(1, 1)), 0, 1)
-    a = np.moveaxis(np.tensordot(Rt, a, axes=(1, 2)), 0, 2)
-    return a.ravel(order="F")
+def _restri(P):
+    """transpose(P ./ sum(P, 1))  (downSample_q.m:10-12)"""
+    colsum = np.asarray(P.sum(axis=0)).ravel()
+    return (P @ sp.diags(1.0 / colsum)).T.tocsr()
 
 
 def downSample_q(nt, nx, ny, q, log_mean=False):
-    """socp/wdot2d/utils/downSample_q.m:4-21; log_mean=True is downSample_barrier.m:4-21
-    (restriction of log(weight), then exp)."""
+    """socp/wdot2d/utils/downSample_q.m:4-21 with the three Kronecker prolongation matrices formed explicitly as sparse
+    matrices, like the reference does; log_mean=True is downSample_barrier.m:4-21 (restriction of log(weight), exp)."""
     nt2, nx2, ny2 = (nt + 1) // 2, (nx + 1) // 2, (ny + 1) // 2
-    bx = (nt - 1) * nx * ny
-    by = bx + nt * (nx - 1) * ny
-    v = np.log(q) if log_mean else q
-    out = np.concatenate([
-        _apply3(v[:bx], (ny, nx, nt - 1), _restrict_linear(ny2), _restrict_linear(nx2), _restrict_nearest(nt2 - 1)),
-        _apply3(v[bx:by], (ny, nx - 1, nt), _restrict_linear(ny2), _restrict_nearest(nx2 - 1), _restrict_linear(nt2)),
-        _apply3(v[by:], (ny - 1, nx, nt), _restrict_nearest(ny2 - 1), _restrict_linear(nx2), _restrict_linear(nt2))])
-    return np.exp(out) if log_mean else out
+    lin, near = _gene_prolongMat1dim_linear, _gene_prolongMat1dim_nearest
+    ProlongT = sp.kron(sp.kron(near(nt2 - 1), lin(nx2)), lin(ny2), format="csc")
+    ProlongX = sp.kron(sp.kron(lin(nt2), near(nx2 - 1)), lin(ny2), format="csc")
+    ProlongY = sp.kron(sp.kron(lin(nt2), lin(nx2)), near(ny2 - 1), format="csc")
+    bxInd = (nt - 1) * nx * ny + 1
+    byInd = bxInd + nt * (nx - 1) * ny
+    v = np.log(q) if log_mean else np.asarray(q, dtype=np.float64)
+    out = np.concatenate([_restri(ProlongT) @ v[:bxInd - 1], _restri(ProlongX) @ v[bxInd - 1:byInd - 1],
+                          _restri(ProlongY) @ v[byInd - 1:]])
+    return np.power(np.e, out) if log_mean else out
 
 
 def downSample_barrier(nt, nx, ny, weight):
     return downSample_q(nt, nx, ny, weight, log_mean=True)
 
 
-def _grad_times(phi, dims):
-    """modelR.grad * phi with the unscaled forward differences of initialize.m:35-39,67-87"""
-    f = phi.reshape(dims, order="F")
-    parts = [(np.diff(f, axis=-1) * (dims[-1] - 1)).ravel(order="F")]
-    if len(dims) == 3:
-        parts.append((np.diff(f, axis=1) * (dims[1] - 1)).ravel(order="F"))
-        parts.append((np.diff(f, axis=0) * (dims[0] - 1)).ravel(order="F"))
-    else:
-        parts.append((np.diff(f, axis=0) * (dims[0] - 1)).ravel(order="F"))
-    return np.concatenate(parts)
-
-
 def jump_nextLevel(var, model, rho0, rho1, nt, weight=None):
     """socp/dot2d/utils/jump_nextLevel.m:5-16 (dot1d twin; wdot2d/utils/jump_nextLevel.m with weight)"""
     one_d = not hasattr(model, "ny")
     cdims = (model.nx, model.nt) if one_d else (model.ny, model.nx, model.nt)
-    phiR = interpolate_phi(var.phi, cdims)
+    phiR = interpolate_phi(var.phi, cdims)                 # :5 interpolate(var, model)
     betaR = interpolate_z(var.beta, cdims)
-    var_init, modelR = initialize(rho0, rho1, nt)
+    var_init, modelR = initialize(rho0, rho1, nt)          # :9
     var.phi, var.beta = phiR, betaR                        # interpolate() returns the same (handle) object
-    var.qInd, var.z = var_init.qInd, var_init.z
-    fdims = (modelR.nx, modelR.nt) if one_d else (modelR.ny, modelR.nx, modelR.nt)
-    var.q = _grad_times(var.phi, fdims)
-    alpha = var_init.alpha
+    var.qInd, var.z = var_init.qInd, var_init.z            # :10-11
+    var.q = np.asarray(modelR.grad @ var.phi).ravel()      # :14  q = grad * phi with the sparse matrix of initialize.m
+    alpha = var_init.alpha                                 # :15
     nb = np.asfortranarray(-var.beta)
     if one_d:
         mexops.mexBFdConj1d(alpha, nb, modelR.nt, modelR.nx, 1.0)
     else:
-        mexops.mexBFdConj(alpha, nb, modelR.nt, modelR.nx, modelR.ny, 1.0)
+        mexops.mexBFdConj(alpha, nb, modelR.nt, modelR.nx, modelR.ny, 1.0)      # :16
     var.alpha = alpha
     if weight is not None:
         modelR.weight = weight

@@ -269,6 +269,13 @@ def test_solver_gateway_ngpu_is_the_single_process_multi_device_mode(mx):
         err = np.max(np.abs(four[f] - one[f])) / np.max(np.abs(one[f]))
         assert err <= 1e-10, (f, err)
     assert four["times"][0, 0] > 0 and four["times"][0, 6] == K
+    # the multilevel driver passes one opts struct to every level (solver_dotsocp2d.m:208): a request for more slabs than
+    # nt / 2 is served with nt / 2 of them (here 8) instead of an error, like the level gateway does
+    many = run(64)
+    np.testing.assert_array_equal(many["iter"], one["iter"])
+    for f in ("phi", "q", "z", "alpha", "beta"):
+        err = np.max(np.abs(many[f] - one[f])) / np.max(np.abs(one[f]))
+        assert err <= 1e-10, (f, err)
     bad = dict(sigma=1.0, maxit=K, tol=0.0, ifCheckStepByStep=0.0, scaling=1.0, tau=1.9, ngpu=0.0)
     S = dict(phi=var.phi.copy(), q=var.q.copy(), alpha=var.alpha.copy(), z=var.z.copy(order="F"), beta=var.beta.copy(order="F"),
              c=model.c.copy(), nx=model.nx, ny=model.ny, nt=model.nt, D=var.D, E=var.E, cScale=var.cScale, dScale=var.dScale,

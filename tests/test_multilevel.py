@@ -62,7 +62,53 @@ def test_downsample_weights():
         assert wc.size == 5 * 5 * 4 + 5 * 4 * 5 + 4 * 5 * 5
         assert wc.min() >= 1 - 1e-12 and wc.max() <= 1e6 * (1 + 1e-12)
         np.testing.assert_allclose(M.downSample_q(nt, nx, ny, np.ones_like(w)), 1.0, atol=1e-14)
-    np.testing.assert_allclose(OM.downSample_barrier(nt, nx, ny, w), PM.downSample_barrier(nt, nx, ny, w), rtol=1e-15)
+    # two implementations (oracle: the reference's explicit sparse Kronecker matrices; package: separable tensor
+    # products): equal up to the order of the additions
+    np.testing.assert_allclose(OM.downSample_barrier(nt, nx, ny, w), PM.downSample_barrier(nt, nx, ny, w), rtol=1e-13)
+    q = rng.standard_normal(w.size)
+    np.testing.assert_allclose(OM.downSample_q(nt, nx, ny, q), PM.downSample_q(nt, nx, ny, q), rtol=0, atol=1e-14)
+
+
+def test_full_weighting_is_a_quarter_of_the_transposed_bilinear_prolongation():
+    """Interior rows of downSample_phi.m:11-15 are the full-weighting stencil [1 2 1; 2 4 2; 1 2 1] / 16 = 1/4 of the
+    transpose of bilinear interpolation (interpolate.m:62-64 in two dimensions): <R v, u> = <v, P u> / 4 for every
+    coarse u that vanishes on the boundary ring.  Ties the restriction of both implementations to the prolongation."""
+    v = rng.standard_normal((17, 17))
+    u = np.zeros((9, 9))
+    u[1:-1, 1:-1] = rng.standard_normal((7, 7))
+    for M in (OM, PM):
+        Pu = M.interpolate_phi(u.ravel(order="F"), (9, 9)).reshape((17, 17), order="F")
+        lhs = np.sum(M.downSample_phi(v) * u)
+        assert abs(lhs - 0.25 * np.sum(v * Pu)) <= 1e-13 * (np.abs(v).sum() + 1)
+    # 1-D: interior rows [1 2 1] / 4 = 1/2 of the transposed linear interpolation (dot1d downSample_phi.m:10)
+    v1 = rng.standard_normal(33)
+    for M in (OM, PM):
+        # P e_c for the unit vectors of the interior coarse nodes: fine values 1/2, 1, 1/2 around node 2 c
+        vc = M.downSample_phi(v1)
+        for c in range(1, 16):
+            assert abs(vc[c] - 0.5 * (0.5 * v1[2 * c - 1] + v1[2 * c] + 0.5 * v1[2 * c + 1])) <= 1e-15 * 4
+
+
+def test_oracle_and_package_transfer_operators_are_separate_implementations():
+    """tests above compare oracle.multilevel with dotsocp_amd.multilevel; that only means something while the two are
+    written differently (round 2's verdict found them textually identical).  The oracle follows the .m files index by
+    index (loops, sparse kron); the package is vectorised."""
+    import difflib
+    import inspect
+    # (jump_nextLevel itself is a ten-line call sequence; its q = grad * phi is the sparse matrix of initialize.m in the
+    # oracle and a difference stencil in the package)
+    for name in ("downSample_phi", "interpolate_phi", "interpolate_z", "downSample_q"):
+        a = inspect.getsource(getattr(OM, name))
+        b = inspect.getsource(getattr(PM, name))
+        assert difflib.SequenceMatcher(None, a, b).ratio() < 0.6, name
+    z = np.asfortranarray(rng.standard_normal((5 * 4 * 2, 10)))
+    np.testing.assert_array_equal(OM.interpolate_z(z, (5, 4, 3)), PM.interpolate_z(z, (5, 4, 3)))
+    z1 = np.asfortranarray(rng.standard_normal((9 * 4, 6)))
+    np.testing.assert_array_equal(OM.interpolate_z(z1, (9, 5)), PM.interpolate_z(z1, (9, 5)))
+    f = rng.standard_normal(9 * 5)
+    np.testing.assert_array_equal(OM.interpolate_phi(f, (9, 5)), PM.interpolate_phi(f, (9, 5)))
+    g = rng.standard_normal(5 * 4 * 3)
+    np.testing.assert_array_equal(OM.interpolate_phi(g, (5, 4, 3)), PM.interpolate_phi(g, (5, 4, 3)))
 
 
 TRANSFERS = pytest.mark.parametrize("transfer", ["device", "host"])
