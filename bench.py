@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--nslabs", type=int, default=1,
                     help="diagnostics: run the time-slab algorithm with this many slabs inside ONE process / GPU")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--rank-share", type=int, default=0, metavar="N",
+                    help="diagnostics: run ONE rank's slab (the middle one) of the N-way time-slab split on this GPU, with the "
+                         "code path of a real rank and its neighbour messages as local copies (tools/loopback_rccl.cpp); "
+                         "T(full grid) / T(this) is the compute-only ceiling of the N-GPU strong-scaling curve")
     return ap.parse_args()
 
 
@@ -211,6 +215,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    share = args.rank_share if args.rank_share > 1 else 0
+    if share:
+        if world != 1 or args.nslabs != 1 or args.workload != "dot2d":
+            raise SystemExit("--rank-share runs one process on one GPU on the dot2d workload")
+        lb = os.path.join(ROOT, "tools", "libloopback_rccl.so")
+        if not os.path.exists(lb):
+            raise SystemExit("tools/libloopback_rccl.so is missing: run __graft_entry__.build()")
+        os.environ["DOTSOCP_RCCL_LIB"] = lb           # read when the communicator is attached
     import torch
     import dotsocp_amd as D
     if args.grid:
@@ -249,7 +261,16 @@ def main():
 
     opts = dict(tau=1.0 if args.method == "ALG2" else 1.9, sigma=1.0, tol=0.0, maxit=args.warmup + args.steps, scaling=True,
                 ifCheckStepByStep=False, time_limit=1e9)
-    if world == 1:
+    if share:
+        # the middle slab of the N-way split: both neighbours exist, every exchange of a real rank takes place
+        weight = None
+        share_rank = share // 2
+        rccl = (bytes(128), share_rank, share)
+        rho0, rho1 = D.get_example_2d("example1", ny, nx)
+        t0s, t1s = D.capi.slab_range(nt, share, share_rank)
+        var, model = D.initialize_slab(rho0, rho1, nt, t0s, t1s)
+        D.InitialScaling(var, model, True, None, dim=2)
+    elif world == 1:
         var, model, rho0, rho1, weight = build_problem(D, args.workload, ny, nx, nt)
     else:
         weight = None
@@ -288,7 +309,7 @@ def main():
     ctx.close()
 
     # per-launch sizes of THIS rank's slab (the whole grid at N = 1)
-    t0s, t1s = D.capi.slab_range(nt, world, rank)
+    t0s, t1s = D.capi.slab_range(nt, share, share // 2) if share else D.capi.slab_range(nt, world, rank)
     ntl = t1s - t0s
     ncl = ntl if t1s < nt else ntl - 1
     Nz = ny * nx * ncl
@@ -336,20 +357,28 @@ def main():
                        "inPALM": "inPALM tau=1.9", "ALG2": "ALG2 tau=1.0", "PALM": "PALM tau=1.9",
                        "acc-ADMM": "acc-ADMM (Halpern, rho=2, restart=100)"}[args.method] + ", levelN=1",
                    "grid": [ny, nx, nt], "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
-                   "parallelism": "1 GPU" if world == 1 else f"{world} time slabs"},
+                   "parallelism": (f"rank share: slab {share // 2} of {share} time slabs on 1 GPU, neighbour messages as local "
+                                   f"copies (timing only, not a valid solve)") if share else
+                                  ("1 GPU" if world == 1 else f"{world} time slabs")},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": proj_ms, "launches": proj_n},
         "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
     }
-    if world > 1 or args.nslabs > 1:
+    if share:
+        out["rank_share"] = {"n": share, "slab": share // 2, "time_nodes": int(ntl),
+                             "kernel_ms_sum": round(sum(v[0] * v[1] for v in times.values()) / max(args.steps, 1), 4),
+                             "note": "kernel_ms_sum = per-iteration sum of the phase timers (HIP events on the launch streams; "
+                                     "phases on the second stream overlap the main one); ms_per_step - overlap-free kernel time = "
+                                     "launch / dependency chain + host"}
+    if world > 1 or args.nslabs > 1 or share:
         # time-slab mode: the timed interval covers both chunk launches of the slab's cone pass on the second stream --
         # they share HBM with the Poisson solve on the main stream and wait for the q halo in between; the N = 1 line
         # is the kernel's roofline figure
         out["roofline"]["note"] = "interval spans two chunk launches overlapped with the phi-step and the halo wait"
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and args.method == "inPALM":
+        if not args.no_cpu_baseline and world == 1 and args.method == "inPALM" and not share:
             out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
