@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
         const bool own = tl >= t0;
         double w[10];
         if (hasCell) {
-            const i64 i = yc + g.ny * (xc + g.nx * tl);
+            const i64 i = yc + g.py * (xc + g.nx * tl);
             double b[10], zz[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];

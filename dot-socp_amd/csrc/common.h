@@ -48,26 +48,36 @@ void set_error(const char *fmt, ...);
 // cell and the forward time difference of phi can be formed locally (`halo` = 1).
 // For the single slab (t0 = 0, ntl = nt, halo = 0) the local layout of q is exactly the
 // reference's q = [q0; bx; by].
+//
+// Rows may be PITCHED: every array indexed by (y, x[, t]) -- phi, c, q0, bx, by, the ten cone planes -- stores its rows
+// `py` doubles apart (py >= ny, a multiple of 16 = 128 bytes), by rows `pyb` apart (unpitched: ny - 1, the reference's
+// layout; pitched: py).  A wavefront's 64 consecutive y then start on a cache-line boundary on the 2^k+1 grids the
+// reference's multilevel driver runs (rows of 1025 doubles straddle five lines instead of four and both ends of every
+// store are partial lines).  Only strides change: extents, loops and sums run over y < ny; the pad entries are zero
+// (weights: one) and are never written.  Host arrays keep the reference layout (converted in upload / download).
 struct Grid {
     i64 ny, nx, nt;        // global dims
+    i64 py, pyb;           // row pitch of node / q0 / bx rows, of by rows
     i64 t0, ntl, ncl;      // slab: first node, #nodes, #cells
     int halo;              // 1: an extra bx/by/phi layer is stored behind the owned ones
     int first, last;       // slab touches the global t = 0 / t = nt-1 boundary
-    i64 plane;             // ny*nx
-    i64 bxLayer, byLayer;  // ny*(nx-1), (ny-1)*nx
+    i64 plane;             // py*nx
+    i64 bxLayer, byLayer;  // py*(nx-1), pyb*nx
     i64 Nphi, Nz;          // owned nodes / cells
     i64 offBx, offBy, NqAlloc;  // local q layout: [q0 | bx (ntl+halo layers) | by (ntl+halo layers)]
     i64 NphiAlloc;         // plane*(ntl+halo)
 
-    __host__ __device__ void set(i64 ny_, i64 nx_, i64 nt_, i64 t0_, i64 ntl_) {
+    __host__ __device__ void set(i64 ny_, i64 nx_, i64 nt_, i64 t0_, i64 ntl_, i64 py_ = 0) {
         ny = ny_; nx = nx_; nt = nt_; t0 = t0_; ntl = ntl_;
+        py = (py_ > ny_) ? py_ : ny_;
+        pyb = (py > ny) ? py : ny - 1;
         first = (t0 == 0);
         last = (t0 + ntl == nt);
         ncl = last ? ntl - 1 : ntl;
         halo = last ? 0 : 1;
-        plane = ny * nx;
-        bxLayer = ny * (nx - 1);
-        byLayer = (ny - 1) * nx;
+        plane = py * nx;
+        bxLayer = py * (nx - 1);
+        byLayer = pyb * nx;
         Nphi = plane * ntl;
         Nz = plane * ncl;
         offBx = Nz;

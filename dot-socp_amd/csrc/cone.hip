@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd(Grid g, double *__restri
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
     if (y >= g.ny || x >= g.nx) return;
-    const i64 i = y + g.ny * (x + g.nx * tl);
+    const i64 i = y + g.py * (x + g.nx * tl);
     const double q0 = q[i];
     z[i] = dF - s * q0;
     z[9 * g.Nz + i] = dF + s * q0;
@@ -84,10 +84,10 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd(Grid g, double *__restri
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         const i64 tt = tl + dt;
-        if (x >= 1) z[(1 + 2 * dt) * g.Nz + i] = sf * bx[g.bxLayer * tt + y + g.ny * (x - 1)];
-        if (x <= g.nx - 2) z[(2 + 2 * dt) * g.Nz + i] = sf * bx[g.bxLayer * tt + y + g.ny * x];
-        if (y >= 1) z[(5 + 2 * dt) * g.Nz + i] = sf * by[g.byLayer * tt + (y - 1) + (g.ny - 1) * x];
-        if (y <= g.ny - 2) z[(6 + 2 * dt) * g.Nz + i] = sf * by[g.byLayer * tt + y + (g.ny - 1) * x];
+        if (x >= 1) z[(1 + 2 * dt) * g.Nz + i] = sf * bx[g.bxLayer * tt + y + g.py * (x - 1)];
+        if (x <= g.nx - 2) z[(2 + 2 * dt) * g.Nz + i] = sf * bx[g.bxLayer * tt + y + g.py * x];
+        if (y >= 1) z[(5 + 2 * dt) * g.Nz + i] = sf * by[g.byLayer * tt + (y - 1) + g.pyb * x];
+        if (y <= g.ny - 2) z[(6 + 2 * dt) * g.Nz + i] = sf * by[g.byLayer * tt + y + g.pyb * x];
     }
 }
 
@@ -109,14 +109,14 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd_conj(Grid g, double *__r
     WPlain W{w, g.Nz};
     if (seg == 0) {
         if (y >= g.ny || x >= g.nx) return;
-        const i64 i = y + g.ny * (x + g.nx * tl);
+        const i64 i = y + g.py * (x + g.nx * tl);
         q[i] = s * (w[9 * g.Nz + i] - w[i]);
     } else if (seg == 1) {
         if (y >= g.ny || x >= g.nx - 1) return;
-        q[g.offBx + g.bxLayer * tl + y + g.ny * x] = sf * gather_bx(g, W, y, x, tl, tail_bx);
+        q[g.offBx + g.bxLayer * tl + y + g.py * x] = sf * gather_bx(g, W, y, x, tl, tail_bx);
     } else {
         if (y >= g.ny - 1 || x >= g.nx) return;
-        q[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x] = sf * gather_by(g, W, y, x, tl, tail_by);
+        q[g.offBy + g.byLayer * tl + y + g.pyb * x] = sf * gather_by(g, W, y, x, tl, tail_by);
     }
 }
 
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_cone_march(Grid g, LoopCoef 
     const i64 tend = (tbeg + MARCH < g.ncl) ? tbeg + MARCH : g.ncl;
     EdgeQuad cur = load_edges(g, q, y, x, tbeg, c.sf);
     for (i64 tl = tbeg; tl < tend; ++tl) {
-        const i64 i = y + g.ny * (x + g.nx * tl);
+        const i64 i = y + g.py * (x + g.nx * tl);
         const EdgeQuad nxt = load_edges(g, q, y, x, tl + 1, c.sf);
         double v[10];
         build_z2(v, q[i], cur, nxt, c.s, c.dF);
@@ -210,14 +210,14 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_gather_tail(Grid g, const do
     const i64 tl = g.ncl - 1;
     auto w = [&](int j, i64 cell) { return z[j * g.Nz + cell] + beta[j * g.Nz + cell]; };
     if (y < g.ny && x < g.nx - 1) {
-        double acc = w(3, y + g.ny * ((x + 1) + g.nx * tl));
-        acc += w(4, y + g.ny * (x + g.nx * tl));
-        tail_bx[y + g.ny * x] = acc;
+        double acc = w(3, y + g.py * ((x + 1) + g.nx * tl));
+        acc += w(4, y + g.py * (x + g.nx * tl));
+        tail_bx[y + g.py * x] = acc;
     }
     if (y < g.ny - 1 && x < g.nx) {
-        double acc = w(7, (y + 1) + g.ny * (x + g.nx * tl));
-        acc += w(8, y + g.ny * (x + g.nx * tl));
-        tail_by[y + (g.ny - 1) * x] = acc;
+        double acc = w(7, (y + 1) + g.py * (x + g.nx * tl));
+        acc += w(8, y + g.py * (x + g.nx * tl));
+        tail_by[y + g.pyb * x] = acc;
     }
 }
 

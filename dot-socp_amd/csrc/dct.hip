@@ -136,10 +136,13 @@ void dct_plan_destroy(DctPlan *p) {
 // Line addressing shared by all axes: line L, element k lives at
 //   (L % nin) + (L / nin) * outerStride + k * nin
 // axis 0: nin = 1, outerStride = n;  axis 1: nin = n0, outerStride = n0*n1;  axis 2: nin = n0*n1.
+// With pitched rows (pitch >= n0) the element stride is no longer the line count per group:
+// axis 0: nin = 1, outerStride = pitch, es = 1;  axis 1: nin = n0, outerStride = pitch*n1, es = pitch;
+// axis 2: nin = n0, outerStride = pitch, es = pitch*n1.  (The power-of-two kernels run unpitched: es == nin there.)
 struct LineMap {
-    i64 nin, outerStride, nLines;
+    i64 nin, outerStride, nLines, es;
     __device__ __forceinline__ i64 base(i64 L) const { return (L % nin) + (L / nin) * outerStride; }
-    __device__ __forceinline__ i64 addr(i64 L, i64 k) const { return base(L) + k * nin; }
+    __device__ __forceinline__ i64 addr(i64 L, i64 k) const { return base(L) + k * es; }
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
 #pragma unroll
             for (int u = 0; u < DCT_BATCH; ++u) {
                 const int k = k0 + u * kstep;
-                gv[u] = (ok && k < n) ? *(const double2 *)(src + lb + (i64)k * map.nin) : make_double2(0.0, 0.0);
+                gv[u] = (ok && k < n) ? *(const double2 *)(src + lb + (i64)k * map.es) : make_double2(0.0, 0.0);
             }
 #pragma unroll
             for (int u = 0; u < DCT_BATCH; ++u) {
@@ -481,7 +484,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
         const bool ok = L < map.nLines;
         const i64 lb = ok ? map.base(L) : 0;
         for (int k = tid >> (lp + 1); k < n; k += DCT_THREADS >> (lp + 1)) {
-            const double g = ok ? src[lb + (i64)k * map.nin] : 0.0;
+            const double g = ok ? src[lb + (i64)k * map.es] : 0.0;
             ((double *)&lds[(l >> 1) * rowStride + padi(stage_pos<MODE>(k, n, lg))])[l & 1] = g;
         }
     }
@@ -563,7 +566,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
                 double2 v;
                 if (MODE == 0) v = dct_post(rr, k, n, lg, ww);
                 else v = rr[padi(bitrev(makhoul(k, n), lg))];
-                *(double2 *)(dst + lb + (i64)k * map.nin) = v;
+                *(double2 *)(dst + lb + (i64)k * map.es) = v;
             }
         }
     } else {
@@ -576,7 +579,7 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
                 double2 v;
                 if (MODE == 0) v = dct_post(rr, k, n, lg, ww);
                 else v = rr[padi(bitrev(makhoul(k, n), lg))];
-                dst[lb + (i64)k * map.nin] = (l & 1) ? v.y : v.x;
+                dst[lb + (i64)k * map.es] = (l & 1) ? v.y : v.x;
             }
         }
     }
@@ -1141,7 +1144,7 @@ __global__ void __launch_bounds__(T, 4) k_dct_strided_wg(const double *__restric
 #pragma unroll
         for (int u = 0; u < DCT_BATCH; ++u) {
             const int k = k0 + u * kstep;
-            gv[u] = (ok && k < n) ? *(const double2 *)(src + lb + (i64)k * map.nin) : make_double2(0.0, 0.0);
+            gv[u] = (ok && k < n) ? *(const double2 *)(src + lb + (i64)k * map.es) : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int u = 0; u < DCT_BATCH; ++u) {
@@ -1158,7 +1161,7 @@ __global__ void __launch_bounds__(T, 4) k_dct_strided_wg(const double *__restric
             double2 v;
             if (MODE == 0) v = dct_post(rr, k, n, lg, ww);
             else v = rr[padi(bitrev(makhoul(k, n), lg))];
-            *(double2 *)(dst + lb + (i64)k * map.nin) = v;
+            *(double2 *)(dst + lb + (i64)k * map.es) = v;
         }
     }
 }
@@ -1278,10 +1281,10 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
             if (AXIS0) {
                 const i64 L = L0 + x_ll + ZSTEP * u;
                 const int j = j0 + x_jj;
-                xreg[u] = (L < map.nLines && j < n) ? src[L * n + j] : 0.0;
+                xreg[u] = (L < map.nLines && j < n) ? src[map.base(L) + j] : 0.0;
             } else {
                 const int j = j0 + x_jj + 2 * u;
-                xreg[u] = (x_ok && j < n) ? src[xbase + (i64)j * map.nin] : 0.0;
+                xreg[u] = (x_ok && j < n) ? src[xbase + (i64)j * map.es] : 0.0;
             }
         }
     };
@@ -1330,11 +1333,11 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
                 if (AXIS0) {
                     const int k = k0 + a * 16 + li;
                     const i64 L = L0 + wave * 32 + b * 16 + lh + 4 * r;
-                    if (k < n && L < map.nLines) dst[L * n + k] = acc[a][b][r];
+                    if (k < n && L < map.nLines) dst[map.base(L) + k] = acc[a][b][r];
                 } else {
                     const int k = k0 + a * 16 + lh + 4 * r;
                     const i64 L = L0 + wave * 32 + b * 16 + li;
-                    if (k < n && L < map.nLines) dst[map.base(L) + (i64)k * map.nin] = acc[a][b][r];
+                    if (k < n && L < map.nLines) dst[map.base(L) + (i64)k * map.es] = acc[a][b][r];
                 }
             }
 }
@@ -1388,7 +1391,7 @@ __global__ void __launch_bounds__(256) k_dct_mfma_split(const double *__restrict
         x_ok = (L0 + x_ll) < map.nLines;
         xbase = x_ok ? map.base(L0 + x_ll) : 0;
     }
-    auto at = [&](i64 L, i64 lbase, int j) { return AXIS0 ? src[L * n + j] : src[lbase + (i64)j * map.nin]; };
+    auto at = [&](i64 L, i64 lbase, int j) { return AXIS0 ? src[map.base(L) + j] : src[lbase + (i64)j * map.es]; };
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         const int par = INV ? ph : (int)blockIdx.z;               // 0: even part, 1: odd part
@@ -1468,8 +1471,8 @@ __global__ void __launch_bounds__(256) k_dct_mfma_split(const double *__restrict
                 const int o = o0 + a * 16 + (AXIS0 ? li : lh + 4 * r);
                 const i64 L = L0 + wave * 32 + b * 16 + (AXIS0 ? lh + 4 * r : li);
                 if (o >= nout || L >= map.nLines) continue;
-                const i64 lbase = AXIS0 ? L * n : map.base(L);
-                const i64 es = AXIS0 ? 1 : map.nin;
+                const i64 lbase = map.base(L);
+                const i64 es = map.es;
                 if (!INV) {
                     dst[lbase + (i64)(2 * o + (int)blockIdx.z) * es] = acc[0][a][b][r];
                 } else {
@@ -1575,9 +1578,9 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     const i64 linesPerBlock = (i64)2 << lp;
     const unsigned blocks = (unsigned)((map.nLines + linesPerBlock - 1) / linesPerBlock);
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
-    const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (map.es % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     // fused t-axis solve, pipelined: eigenvalue tables in LDS, a tile = consecutive columns of one x
-    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 7 && lg <= 10 && map.outerStride == 0) {
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 7 && lg <= 10 && map.outerStride == 0 && map.es == map.nin) {
         const i64 tileLines = ((i64)2 << TS_LG_CPLX) / n;
         const i64 nxv = sa.ny > 0 ? sa.nplane / sa.ny : 0;
         const size_t ldsPipe = (((size_t)2 << TS_LG_CPLX) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
@@ -1602,7 +1605,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
         }
     }
     // pipelined persistent kernel (see k_dct_axis0_pipe): whole tiles of 4096 complex values, the chip filled twice over
-    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 10) {
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 10 && map.es == map.nin) {
         const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
         const int G = device_cus() & ~15;
         if (map.nin % tileLines == 0 && map.nLines % tileLines == 0 && G >= 16 && map.nLines / tileLines >= 2 * (i64)G &&
@@ -1678,13 +1681,25 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
 }
 
 int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nplane, i64 line0, i64 nl,
-                       i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st) {
+                       i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st,
+                       i64 pitch0) {
     if (p->n != nt || !dct_plan_has_tsolve(p)) {
         set_error("fused t-axis solve needs a power-of-two nt or one of the prime-factor lengths");
         return DOTSOCP_EINVAL;
     }
+    const bool pitched = pitch0 > ny;
+    if (pitched && (line0 != 0 || nl != nplane || nplane % ny != 0)) {
+        set_error("fused t-axis solve: pitched rows need whole layers");
+        return DOTSOCP_EINVAL;
+    }
     if (p->log2n <= 0) {
         if (nl <= 0) return 0;
+        if (pitched) {
+            // whole layers: nx rows of ny lines, rows pitch0 apart, time nodes pitch0 * nx apart
+            const i64 nxv = nplane / ny;
+            PfaSolveArgs a{kscale, cy, cx, ct, ny, 0, ny};
+            return pfa_launch_strided(p->pfa, src, dst, ny, nxv, pitch0, pitch0 * nxv, pitch0, pitch0 * nxv, 2, &a, st);
+        }
         PfaSolveArgs a{kscale, cy, cx, ct, ny, line0, 0};
         return pfa_launch_strided(p->pfa, src, dst, nl, 1, 0, nl, 0, nl, 2, &a, st);
     }
@@ -1692,13 +1707,20 @@ int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny,
     map.nin = nl;
     map.outerStride = 0;
     map.nLines = nl;
+    map.es = nl;
+    if (pitched) {          // whole layers with pitched rows: line L = (y, x) = (L % ny, L / ny) starts at y + pitch0 * x
+        map.nin = ny;
+        map.outerStride = pitch0;
+        map.es = pitch0 * (nplane / ny);
+    }
     if (map.nLines <= 0) return 0;
     SolveArgs sa{ny, line0, nplane, kscale, cy, cx, ct};
     return launch_strided(2, p, src, dst, map, sa, st);
 }
 
 int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis, int inverse,
-                    hipStream_t st) {
+                    hipStream_t st, i64 pitch0) {
+    const i64 P0 = pitch0 > n0 ? pitch0 : n0;           // row pitch of both arrays
     const i64 dims[3] = {n0, n1, n2};
     const i64 n = dims[axis];
     const i64 total = n0 * n1 * n2;
@@ -1708,15 +1730,24 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         return DOTSOCP_EINVAL;
     }
     if (n == 1) {
+        const i64 all = P0 * n1 * n2;                     // pad entries travel with the rows
         if (src != dst)
-            hipLaunchKernelGGL(k_copy, dim3(launch_blocks(total, 256, 1 << 14)), dim3(256), 0, st, src, dst, total);
+            hipLaunchKernelGGL(k_copy, dim3(launch_blocks(all, 256, 1 << 14)), dim3(256), 0, st, src, dst, all);
         DS_HIP(hipGetLastError());
         return 0;
     }
     LineMap map;
-    if (axis == 0) { map.nin = 1; map.outerStride = n; }
-    else if (axis == 1) { map.nin = n0; map.outerStride = n0 * n1; }
-    else { map.nin = n0 * n1; map.outerStride = 0; }
+    if (P0 == n0) {
+        if (axis == 0) { map.nin = 1; map.outerStride = n; map.es = 1; }
+        else if (axis == 1) { map.nin = n0; map.outerStride = n0 * n1; map.es = n0; }
+        else { map.nin = n0 * n1; map.outerStride = 0; map.es = n0 * n1; }
+    } else {
+        // (a power-of-two n0 is never pitched; power-of-two n1 / n2 beside a pitched n0 take the kernels that honour map.es)
+        if (p->log2n > 0 && axis == 0) { set_error("power-of-two transforms along y run on unpitched rows"); return DOTSOCP_EINVAL; }
+        if (axis == 0) { map.nin = 1; map.outerStride = P0; map.es = 1; }
+        else if (axis == 1) { map.nin = n0; map.outerStride = P0 * n1; map.es = P0; }
+        else { map.nin = n0; map.outerStride = P0; map.es = P0 * n1; }
+    }
     map.nLines = total / n;
     if (p->log2n > 0 && axis != 0) {
         SolveArgs sa{};
@@ -1794,9 +1825,9 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         // DOTSOCP_PFA=0: the dense product also for the lengths that have a prime-factor transform
         static const bool pfa_on = !(getenv("DOTSOCP_PFA") && atoi(getenv("DOTSOCP_PFA")) == 0);
         if (p->pfa && pfa_on) {
-            if (axis == 0) return pfa_launch_axis0(p->pfa, src, dst, map.nLines, n0, n0, inverse, st);
-            if (axis == 1) return pfa_launch_strided(p->pfa, src, dst, n0, n2, n0 * n1, n0, n0 * n1, n0, inverse ? 1 : 0, nullptr, st);
-            return pfa_launch_strided(p->pfa, src, dst, n0, n1, n0, n0 * n1, n0, n0 * n1, inverse ? 1 : 0, nullptr, st);
+            if (axis == 0) return pfa_launch_axis0(p->pfa, src, dst, map.nLines, P0, P0, inverse, st);
+            if (axis == 1) return pfa_launch_strided(p->pfa, src, dst, n0, n2, P0 * n1, P0, P0 * n1, P0, inverse ? 1 : 0, nullptr, st);
+            return pfa_launch_strided(p->pfa, src, dst, n0, n1, P0, P0 * n1, P0, P0 * n1, inverse ? 1 : 0, nullptr, st);
         }
         if (src == dst) {
             set_error("dense DCT path needs distinct src/dst");
@@ -1858,7 +1889,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
 
 // data ./= kscale * ((CY[ky] + CX[kx]) + CT[kt]) with the zero eigenvalue replaced by 1
 // (initialize_FFTkernel.m:6-15, solver_socp_inPALM.m:96).
-__global__ void __launch_bounds__(256) k_spectral_divide(double *__restrict__ data, i64 ny, i64 nxl, i64 nt, i64 x0,
+__global__ void __launch_bounds__(256) k_spectral_divide(double *__restrict__ data, i64 ny, i64 py, i64 nxl, i64 nt, i64 x0,
                                                           double kscale, const double *__restrict__ cy,
                                                           const double *__restrict__ cx,
                                                           const double *__restrict__ ct) {
@@ -1868,7 +1899,7 @@ __global__ void __launch_bounds__(256) k_spectral_divide(double *__restrict__ da
     if (y >= ny || x >= nxl) return;
     double lam = (cy[y] + cx[x0 + x]) + ct[t];
     if (lam == 0.0) lam = 1.0;
-    const i64 i = y + ny * (x + nxl * t);
+    const i64 i = y + py * (x + nxl * t);
     data[i] = data[i] / (kscale * lam);
 }
 
@@ -1896,11 +1927,11 @@ int launch_spectral_divide_pencil(double *data, i64 ny, i64 nplane, i64 line0, i
 }
 
 int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl, double kscale, const double *cy,
-                           const double *cx, const double *ct, hipStream_t st) {
+                           const double *cx, const double *ct, hipStream_t st, i64 pitch0) {
     (void)nx;
     if (ny * nxl * nt <= 0) return 0;
     dim3 grid((unsigned)((ny + 63) / 64), (unsigned)((nxl + 3) / 4), (unsigned)nt);
-    hipLaunchKernelGGL(k_spectral_divide, grid, dim3(64, 4), 0, st, data, ny, nxl, nt, x0, kscale, cy, cx, ct);
+    hipLaunchKernelGGL(k_spectral_divide, grid, dim3(64, 4), 0, st, data, ny, pitch0 > ny ? pitch0 : ny, nxl, nt, x0, kscale, cy, cx, ct);
     DS_HIP(hipGetLastError());
     return 0;
 }

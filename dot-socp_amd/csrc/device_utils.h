@@ -65,10 +65,10 @@ __device__ __forceinline__ EdgeQuad load_edges(const Grid &g, const double *__re
     const double *bx = (g.nx >= 2) ? q + g.offBx + g.bxLayer * tt : q;
     const double *by = (g.ny >= 2) ? q + g.offBy + g.byLayer * tt : q;
     const i64 nxe = (g.nx >= 2) ? g.nx - 2 : 0, nye = (g.ny >= 2) ? g.ny - 2 : 0;   // last edge index
-    const i64 rowy = (g.ny >= 2) ? g.ny - 1 : 0;                                     // by row length
+    const i64 rowy = (g.ny >= 2) ? g.pyb : 0;                                        // by row stride
     const i64 xm = (x >= 1) ? x - 1 : 0, xp = (x <= nxe) ? x : nxe;
     const i64 ym = (y >= 1) ? y - 1 : 0, yp = (y <= nye) ? y : nye;
-    const double vxm = bx[y + g.ny * xm], vxp = bx[y + g.ny * xp];
+    const double vxm = bx[y + g.py * xm], vxp = bx[y + g.py * xp];
     const double vym = by[ym + rowy * x], vyp = by[yp + rowy * x];
     EdgeQuad e;
     e.xm = (x >= 1) ? sf * vxm : 0.0;
@@ -93,14 +93,14 @@ __device__ __forceinline__ double gather_bx(const Grid &g, const W &w, i64 y, i6
                                             const double *__restrict__ tail_bx) {
     double acc = 0.0;
     if (tl < g.ncl) {
-        acc += w(1, y + g.ny * ((xe + 1) + g.nx * tl));
-        acc += w(2, y + g.ny * (xe + g.nx * tl));
+        acc += w(1, y + g.py * ((xe + 1) + g.nx * tl));
+        acc += w(2, y + g.py * (xe + g.nx * tl));
     }
     if (tl >= 1) {
-        acc += w(3, y + g.ny * ((xe + 1) + g.nx * (tl - 1)));
-        acc += w(4, y + g.ny * (xe + g.nx * (tl - 1)));
+        acc += w(3, y + g.py * ((xe + 1) + g.nx * (tl - 1)));
+        acc += w(4, y + g.py * (xe + g.nx * (tl - 1)));
     } else if (!g.first) {
-        acc += tail_bx[y + g.ny * xe];
+        acc += tail_bx[y + g.py * xe];
     }
     return acc;
 }
@@ -110,14 +110,14 @@ __device__ __forceinline__ double gather_by(const Grid &g, const W &w, i64 ye, i
                                             const double *__restrict__ tail_by) {
     double acc = 0.0;
     if (tl < g.ncl) {
-        acc += w(5, (ye + 1) + g.ny * (x + g.nx * tl));
-        acc += w(6, ye + g.ny * (x + g.nx * tl));
+        acc += w(5, (ye + 1) + g.py * (x + g.nx * tl));
+        acc += w(6, ye + g.py * (x + g.nx * tl));
     }
     if (tl >= 1) {
-        acc += w(7, (ye + 1) + g.ny * (x + g.nx * (tl - 1)));
-        acc += w(8, ye + g.ny * (x + g.nx * (tl - 1)));
+        acc += w(7, (ye + 1) + g.py * (x + g.nx * (tl - 1)));
+        acc += w(8, ye + g.py * (x + g.nx * (tl - 1)));
     } else if (!g.first) {
-        acc += tail_by[ye + (g.ny - 1) * x];
+        acc += tail_by[ye + g.pyb * x];
     }
     return acc;
 }
@@ -142,19 +142,19 @@ template <bool WEIGHTED>
 __device__ __forceinline__ double rhs_value(const RhsArgs &a, i64 y, i64 x, i64 tl) {
     const Grid &g = a.g;
     auto u = [&](i64 k) { return WEIGHTED ? a.weight[k] * a.q[k] - a.alpha[k] : a.q[k] - a.alpha[k]; };
-    const i64 node = y + g.ny * (x + g.nx * tl);
+    const i64 node = y + g.py * (x + g.nx * tl);
     double r = 0.0;
     if (tl >= 1)
         r += a.at * u(node - g.plane);
     else if (!g.first)
-        r += a.at * a.u0_prev[y + g.ny * x];
+        r += a.at * a.u0_prev[y + g.py * x];
     if (tl < g.ncl) r += (-a.at) * u(node);
     const i64 bxo = g.offBx + g.bxLayer * tl;
-    if (x >= 1) r += a.ax * u(bxo + y + g.ny * (x - 1));
-    if (x <= g.nx - 2) r += (-a.ax) * u(bxo + y + g.ny * x);
+    if (x >= 1) r += a.ax * u(bxo + y + g.py * (x - 1));
+    if (x <= g.nx - 2) r += (-a.ax) * u(bxo + y + g.py * x);
     const i64 byo = g.offBy + g.byLayer * tl;
-    if (y >= 1) r += a.ay * u(byo + (y - 1) + (g.ny - 1) * x);
-    if (y <= g.ny - 2) r += (-a.ay) * u(byo + y + (g.ny - 1) * x);
+    if (y >= 1) r += a.ay * u(byo + (y - 1) + g.pyb * x);
+    if (y <= g.ny - 2) r += (-a.ay) * u(byo + y + g.pyb * x);
     return r + a.cvec[node];
 }
 

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
         const bool own = tl >= t0;                      // false only for the recomputed cell in front of the chunk
         double w[10];
         if (hasCell) {
-            const i64 i = yc + g.ny * (xc + g.nx * tl);
+            const i64 i = yc + g.py * (xc + g.nx * tl);
             const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
             double b[10], v[10];
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 bool tile_xcd_remap(const Grid &g) {
     static const int forced = getenv("DOTSOCP_XCD") ? atoi(getenv("DOTSOCP_XCD")) : -1;
     if (forced >= 0) return forced != 0;
-    return (g.ny % 16) != 0;
+    return (g.py % 16) != 0;
 }
 
 bool cone_split_enabled() {

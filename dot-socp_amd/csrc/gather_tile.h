@@ -28,7 +28,7 @@ __device__ __forceinline__ void gather_emit(const Grid &g, double sf, double2 (&
     __syncthreads();
     if (store) {
         if (x < g.nx - 1) {
-            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
             if (xl < XB - 1) {
                 const double2 r = xch[gc.par][xl + 1][lane];
                 double acc = r.x + w[2];
@@ -44,7 +44,7 @@ __device__ __forceinline__ void gather_emit(const Grid &g, double sf, double2 (&
     const double u5 = __shfl_down(w[5], 1, 64), u7 = __shfl_down(gc.p7, 1, 64);
     if (store) {
         if (y < g.ny - 1) {
-            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            const i64 e = g.offBy + g.byLayer * tl + y + g.pyb * x;
             if (lane < 63) {
                 double acc = u5 + w[6];
                 acc += u7;

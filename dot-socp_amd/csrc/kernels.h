@@ -112,6 +112,7 @@ int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, doubl
 int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, double *betaf, double *neg, double sc_in0,
                         double sc_in1, double sc_out, hipStream_t st, i64 tc0 = 0, i64 Nzc = -1);
 int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t st);
+int launch_fill(double *x, i64 n, double v, hipStream_t st);
 // slab-aware: `out` holds the slab's own layers (ntl node layers resp. ncl cell layers); a_prev: launch_out_tail of the
 // left neighbour (nullptr on the first slab)
 int launch_outputs(const Grid &g, const double *q, const double *alpha, const double *weight, const double *rho0,
@@ -245,22 +246,25 @@ struct DctPlan;   // twiddles / dense matrices for one axis length
 DctPlan *dct_plan_create(i64 n);
 void dct_plan_destroy(DctPlan *p);
 // Orthonormal DCT-II (inverse=0) / DCT-III (inverse=1) along one axis of an [n0][n1][n2] array
-// (n0 fastest), src -> dst.  axis = 0, 1 or 2.  src == dst is allowed for power-of-two lengths only.
+// (n0 fastest), src -> dst.  axis = 0, 1 or 2.  src == dst is allowed for power-of-two and prime-factor lengths.
+// pitch0 > n0: the rows of both arrays are pitch0 doubles apart ([pitch0][n1][n2] with n0 valid entries per row);
+// power-of-two n0 is never pitched.
 int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i64 n1, i64 n2, int axis,
-                    int inverse, hipStream_t st);
+                    int inverse, hipStream_t st, i64 pitch0 = 0);
 // Power-of-two nt only: DCT-II along t, spectral division, DCT-III along t in ONE pass over a
 // pencil [nl][nt]: the columns line0 .. line0+nl-1 of the ny*nx = nplane (y, x) columns (y fastest),
 // all nt time nodes; src -> dst (may alias).
 bool dct_plan_is_pow2(const DctPlan *p);
 bool dct_plan_has_tsolve(const DctPlan *p);   // fused forward / divide / inverse pass along t available
 int launch_dct_t_solve(const DctPlan *p, const double *src, double *dst, i64 ny, i64 nplane, i64 line0, i64 nl,
-                       i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st);
+                       i64 nt, double kscale, const double *cy, const double *cx, const double *ct, hipStream_t st,
+                       i64 pitch0 = 0);   // pitch0 > ny: whole layers (line0 = 0, nl = nplane) with pitched rows
 // same pencil, non-power-of-two nt: spectral division only (between two dense DCT passes)
 int launch_spectral_divide_pencil(double *data, i64 ny, i64 nplane, i64 line0, i64 nl, i64 nt, double kscale,
                                   const double *cy, const double *cx, const double *ct, hipStream_t st);
 // data[i] /= kscale * lambda(i)  with lambda the DCT eigenvalues of initialize_FFTkernel.m:6-15
 // for global dims (ny, nx, nt); the local block covers x in [x0, x0+nxl) (pencil mode) and all y, t.
 int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl, double kscale,
-                           const double *cy, const double *cx, const double *ct, hipStream_t st);
+                           const double *cy, const double *cx, const double *ct, hipStream_t st, i64 pitch0 = 0);
 
 }  // namespace dotsocp

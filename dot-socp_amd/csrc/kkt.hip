@@ -45,9 +45,9 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
         if (tl >= g.ncl) return 0.0;
         if (tl < 0) {
             if (g.first) return 0.0;
-            return k.kappa * halo.a0w_prev[yy + g.ny * xx];
+            return k.kappa * halo.a0w_prev[yy + g.py * xx];
         }
-        const i64 cidx = yy + g.ny * (xx + g.nx * tl);
+        const i64 cidx = yy + g.py * (xx + g.nx * tl);
         return k.kappa * (wgt(cidx) * alpha[cidx]);
     };
     auto rho_node = [&](i64 yy, i64 xx, i64 tl) { return (rhoT_at(yy, xx, tl - 1) + rhoT_at(yy, xx, tl)) / 2.0; };
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
     };
     if (inb) {
         for (i64 tl = tbeg; tl < tend; ++tl) {
-            const i64 node = y + g.ny * (x + g.nx * tl);
+            const i64 node = y + g.py * (x + g.nx * tl);
             const i64 bxo = g.offBx + g.bxLayer * tl, byo = g.offBy + g.byLayer * tl;
             // ---- node: A' alpha - c, <c, phi>, ||phi||^2 ----
             if (PART & 1) {
@@ -75,18 +75,18 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
                 if (tl >= 1)
                     r += c.at * alpha[node - g.plane];
                 else if (!g.first)
-                    r += c.at * halo.a0_prev[y + g.ny * x];
+                    r += c.at * halo.a0_prev[y + g.py * x];
                 if (tl < g.ncl) r += (-c.at) * alpha[node];
-                if (x >= 1) r += c.ax * alpha[bxo + y + g.ny * (x - 1)];
-                if (x <= g.nx - 2) r += (-c.ax) * alpha[bxo + y + g.ny * x];
-                if (y >= 1) r += c.ay * alpha[byo + (y - 1) + (g.ny - 1) * x];
-                if (y <= g.ny - 2) r += (-c.ay) * alpha[byo + y + (g.ny - 1) * x];
+                if (x >= 1) r += c.ax * alpha[bxo + y + g.py * (x - 1)];
+                if (x <= g.nx - 2) r += (-c.ax) * alpha[bxo + y + g.py * x];
+                if (y >= 1) r += c.ay * alpha[byo + (y - 1) + g.pyb * x];
+                if (y <= g.ny - 2) r += (-c.ay) * alpha[byo + y + g.pyb * x];
                 const double cv = cvec[node], pv = phi[node];
                 r = r - cv;
                 // A' alpha - c of the node for launch_rhs_sigma_fix.  The right-hand side it corrects is the q-step's, which
                 // on a slab's first layer still lacks the left neighbour's cell (k_rhs_fixup adds it later, from the
                 // scaled alpha): the same term is left out here
-                if (resid) resid[node] = (tl == 0 && !g.first) ? r - c.at * halo.a0_prev[y + g.ny * x] : r;
+                if (resid) resid[node] = (tl == 0 && !g.first) ? r - c.at * halo.a0_prev[y + g.py * x] : r;
                 S[S_DUAL1] += r * r;
                 S[S_CPHI] += cv * pv;
                 S[S_PHI2] += pv * pv;
@@ -140,9 +140,9 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
             }
             // ---- bx edge (y, x+1/2, t) ----
             if ((PART & 4) && x < g.nx - 1) {
-                const i64 idx = bxo + y + g.ny * x;
+                const i64 idx = bxo + y + g.py * x;
                 double tmp = (-c.ax) * phi[node];
-                tmp += c.ax * phi[node + g.ny];
+                tmp += c.ax * phi[node + g.py];
                 const double q2b = c.sf * gather_bx(g, WB, y, x, tl, halo.btail_bx);
                 edge_sums(idx, tmp, q2b);
                 const double rm = (rho_node(y, x, tl) + rho_node(y, x + 1, tl)) / 2.0;
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
             }
             // ---- by edge (y+1/2, x, t) ----
             if ((PART & 8) && y < g.ny - 1) {
-                const i64 idx = byo + y + (g.ny - 1) * x;
+                const i64 idx = byo + y + g.pyb * x;
                 double tmp = (-c.ay) * phi[node];
                 tmp += c.ay * phi[node + 1];
                 const double q2b = c.sf * gather_by(g, WB, y, x, tl, halo.btail_by);
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
             const bool own = (tl >= t0) && inb;
             double b[10];
             if (hasCell) {
-                const i64 i = yc + g.ny * (xc + g.nx * tl);
+                const i64 i = yc + g.py * (xc + g.nx * tl);
                 const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
                 const EdgeQuad nxto = load_edges(g, a.q_old, yc, xc, tl + 1, c.sf);
                 const double q0 = a.q[i];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 const bool sumLayer = (tl < g.ntl) && !(tl == 0 && !g.first);
                 if (own) {
                     if (x < g.nx - 1) {
-                        const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+                        const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
                         if (xl < TILE_X - 1) {
                             if (sumLayer) {
                             const double2 r = xch[par][xl + 1][lane];
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 const double u5 = __shfl_down(b[5], 1, 64), u7 = __shfl_down(p7, 1, 64);
                 if (own) {
                     if (y < g.ny - 1) {
-                        const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+                        const i64 e = g.offBy + g.byLayer * tl + y + g.pyb * x;
                         if (lane < 63) {
                             if (sumLayer) {
                                 double acc = u5 + b[6];
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
     auto wgt = [&](i64 idx) { return WEIGHTED ? weight[idx] : 1.0; };
     auto rhoT_at = [&](i64 yy, i64 xx, i64 tl) -> double {
         if (tl < 0 || tl >= g.ncl) return 0.0;
-        const i64 cidx = yy + g.ny * (xx + g.nx * tl);
+        const i64 cidx = yy + g.py * (xx + g.nx * tl);
         return k.kappa * (wgt(cidx) * alpha[cidx]);
     };
     auto rho_node = [&](i64 yy, i64 xx, i64 tl) { return (rhoT_at(yy, xx, tl - 1) + rhoT_at(yy, xx, tl)) / 2.0; };
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
     if (DIR == 0) {
         const i64 y = u, x = (i64)blockIdx.y * TILE_X + (TILE_X - 1);
         if (y < g.ny && x < g.nx - 1) {
-            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
             const double rm = (rho_node(y, x, tl) + rho_node(y, x + 1, tl)) / 2.0;
             const double rb = k.dsD * (rm * q[e]);
             const double m = k.kappa * (wgt(e) * alpha[e]);
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
     } else {
         const i64 x = u, y = (i64)blockIdx.y * 64 + 63;
         if (x < g.nx && y < g.ny - 1) {
-            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            const i64 e = g.offBy + g.byLayer * tl + y + g.pyb * x;
             const double rm = (rho_node(y, x, tl) + rho_node(y + 1, x, tl)) / 2.0;
             const double rb = k.dsD * (rm * q[e]);
             const double m = k.kappa * (wgt(e) * alpha[e]);

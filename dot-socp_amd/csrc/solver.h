@@ -124,7 +124,10 @@ struct Solver {
     int xcopy(Slab &from, const double *src, Slab &to, double *dst, i64 count);
     int xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, double *dst, size_t dpitch, size_t width,
                 size_t height);
+    i64 row_pitch() const;             // row pitch of this context's device arrays (ny unless the single slab is pitched)
     int sync_all();                    // host waits for every stream of every slab
+    // rows of `rowlen` doubles between a device array with rows `pitch` apart and a host array in the reference layout
+    int copy_rows(double *dev, double *host, i64 rowlen, i64 pitch, i64 nrows, bool up, hipStream_t st);
     int fork_z();                      // every slab's second stream starts behind what its main stream holds so far
     bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process

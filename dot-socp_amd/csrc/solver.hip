@@ -286,6 +286,16 @@ int Solver::ensure_alloc() {
     return 0;
 }
 
+// Row pitch of the device arrays (common.h: Grid::py).  The single slab of a one-GPU context stores rows whose length is
+// no multiple of 16 doubles -- the 2^k+1 grids of the reference's multilevel driver -- padded to the next multiple of
+// 128 bytes; time-slab contexts keep the reference layout (their messages and the partitioned t-solve index the
+// (y, x) columns of a layer linearly).  DOTSOCP_PITCH=0: never.
+i64 Solver::row_pitch() const {
+    static const bool on = !(getenv("DOTSOCP_PITCH") && atoi(getenv("DOTSOCP_PITCH")) == 0);
+    if (!on || world != 1 || ny <= 16 || ny % 16 == 0) return ny;
+    return (ny + 15) / 16 * 16;
+}
+
 int Solver::alloc_slabs(int first, int count) {
     free_slabs();
     peer_ok = true;
@@ -317,7 +327,7 @@ int Solver::alloc_slabs(int first, int count) {
         if (!s.res) return DOTSOCP_EHIP;
         i64 t0, t1;
         dotsocp_slab_range_impl(nt, world, s.index, &t0, &t1);
-        s.g.set(ny, nx, nt, t0, t1 - t0);
+        s.g.set(ny, nx, nt, t0, t1 - t0, row_pitch());
         const Grid &g = s.g;
         DS_CHECK(dzalloc(&s.phi, g.NphiAlloc, s.st));
         DS_CHECK(dzalloc(&s.q, g.NqAlloc, s.st));
@@ -325,14 +335,25 @@ int Solver::alloc_slabs(int first, int count) {
         DS_CHECK(dzalloc(&s.z, 10 * g.Nz, s.st));
         DS_CHECK(dzalloc(&s.beta, 10 * g.Nz, s.st));
         DS_CHECK(dzalloc(&s.c, g.Nphi, s.st));
-        DS_CHECK(dmalloc(&s.w0, g.Nphi));
-        DS_CHECK(dmalloc(&s.w1, g.Nphi));
-        if (prob.weighted) DS_CHECK(dzalloc(&s.weight, g.NqAlloc, s.st));
+        // pitched rows: the pad entries are never written by the tile kernels, so they are zeroed once here -- the few
+        // kernels that stream over whole arrays (scalings, sums of squares) then leave them zero / add nothing
+        if (g.py > g.ny) {
+            DS_CHECK(dzalloc(&s.w0, g.Nphi, s.st));
+            DS_CHECK(dzalloc(&s.w1, g.Nphi, s.st));
+        } else {
+            DS_CHECK(dmalloc(&s.w0, g.Nphi));
+            DS_CHECK(dmalloc(&s.w1, g.Nphi));
+        }
+        if (prob.weighted) {
+            DS_CHECK(dmalloc(&s.weight, g.NqAlloc));
+            DS_CHECK(launch_fill(s.weight, g.NqAlloc, 1.0, s.st));      // pad entries of a weight are ones (x ./ w stays finite)
+        }
         if (fused) {
             fused_geometry(g, s.fg);
             DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, s.st));
             DS_CHECK(dzalloc(&s.q2, g.NqAlloc, s.st));
-            DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
+            if (g.py > g.ny) DS_CHECK(dzalloc(&s.beta2, 10 * g.Nz, s.st));
+            else DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
             DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, s.st));
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, s.st));
             DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, s.st));
@@ -816,32 +837,44 @@ i64 Solver::field_len(int field) const {
     }
 }
 
+// rows of `rowlen` doubles: device rows `pitch` apart, host rows contiguous (reference layout)
+int Solver::copy_rows(double *dev, double *host, i64 rowlen, i64 pitch, i64 nrows, bool up, hipStream_t st) {
+    if (rowlen <= 0 || nrows <= 0) return 0;
+    if (pitch == rowlen) {
+        if (up) DS_HIP(hipMemcpyAsync(dev, host, sizeof(double) * rowlen * nrows, hipMemcpyHostToDevice, st));
+        else DS_HIP(hipMemcpyAsync(host, dev, sizeof(double) * rowlen * nrows, hipMemcpyDeviceToHost, st));
+        return 0;
+    }
+    if (up) DS_HIP(hipMemcpy2DAsync(dev, sizeof(double) * pitch, host, sizeof(double) * rowlen, sizeof(double) * rowlen,
+                                    (size_t)nrows, hipMemcpyHostToDevice, st));
+    else DS_HIP(hipMemcpy2DAsync(host, sizeof(double) * rowlen, dev, sizeof(double) * pitch, sizeof(double) * rowlen,
+                                 (size_t)nrows, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
 static int copy_field(Solver &S, int field, double *host, bool up) {
     const i64 ny = S.ny, nx = S.nx;
     i64 ntn = S.nt, ntc = S.nt - 1;
     if (S.remote()) { ntn = S.slabs[0].g.ntl; ntc = S.slabs[0].g.ncl; }
-    const i64 NzG = ny * nx * ntc;
-    const i64 bxG = NzG, byG = NzG + ny * (nx - 1) * ntn;
-    hipStream_t cur = nullptr;
-    auto cp = [&](double *dev, double *h, i64 n) -> int {
-        if (n <= 0) return 0;
-        if (up) DS_HIP(hipMemcpyAsync(dev, h, sizeof(double) * n, hipMemcpyHostToDevice, cur));
-        else DS_HIP(hipMemcpyAsync(h, dev, sizeof(double) * n, hipMemcpyDeviceToHost, cur));
-        return 0;
-    };
+    // host side: the reference layout q = [q0 (ny, nx, nt-1) ; bx (ny, nx-1, nt) ; by (ny-1, nx, nt)]; device side: rows
+    // py (by: pyb) doubles apart (common.h)
+    const i64 hplane = ny * nx, hbx = ny * (nx - 1), hby = (ny - 1) * nx;
+    const i64 NzG = hplane * ntc;
+    const i64 bxG = NzG, byG = NzG + hbx * ntn;
     for (auto &s : S.slabs) {
         DS_CHECK(S.use(s));
-        cur = s.st;
+        hipStream_t cur = s.st;
         const Grid &g = s.g;
         const i64 t0 = S.remote() ? 0 : g.t0;
+        auto nodes = [&](double *dev, double *h, i64 layers) { return S.copy_rows(dev, h, ny, g.py, nx * layers, up, cur); };
         switch (field) {
-            case DOTSOCP_F_PHI: DS_CHECK(cp(s.phi, host + g.plane * t0, g.Nphi)); break;
-            case DOTSOCP_F_C: DS_CHECK(cp(s.c, host + g.plane * t0, g.Nphi)); break;
+            case DOTSOCP_F_PHI: DS_CHECK(nodes(s.phi, host + hplane * t0, g.ntl)); break;
+            case DOTSOCP_F_C: DS_CHECK(nodes(s.c, host + hplane * t0, g.ntl)); break;
             case DOTSOCP_F_Q: case DOTSOCP_F_ALPHA: case DOTSOCP_F_WEIGHT: {
                 double *d = field == DOTSOCP_F_Q ? s.q : (field == DOTSOCP_F_ALPHA ? s.alpha : s.weight);
-                DS_CHECK(cp(d, host + g.plane * t0, g.Nz));
-                DS_CHECK(cp(d + g.offBx, host + bxG + g.bxLayer * t0, g.bxLayer * g.ntl));
-                DS_CHECK(cp(d + g.offBy, host + byG + g.byLayer * t0, g.byLayer * g.ntl));
+                DS_CHECK(nodes(d, host + hplane * t0, g.ncl));
+                DS_CHECK(S.copy_rows(d + g.offBx, host + bxG + hbx * t0, ny, g.py, (nx - 1) * g.ntl, up, cur));
+                DS_CHECK(S.copy_rows(d + g.offBy, host + byG + hby * t0, ny - 1, g.pyb, nx * g.ntl, up, cur));
                 break;
             }
             case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
@@ -850,7 +883,7 @@ static int copy_field(Solver &S, int field, double *host, bool up) {
                 if (up && S.prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, cur));
                 for (int j = 0; j < K; ++j) {
                     const int pj = S.prob.dim == 1 ? k1dCols[j] : j;
-                    DS_CHECK(cp(d + pj * g.Nz, host + j * NzG + g.plane * t0, g.Nz));
+                    DS_CHECK(nodes(d + pj * g.Nz, host + j * NzG + hplane * t0, g.ncl));
                 }
                 break;
             }
@@ -1104,8 +1137,8 @@ int Solver::poisson_all() {
     const bool tp2 = dct_plan_has_tsolve(devres[0]->pt);
     FOR_SLABS(s) {
         const Grid &g = s.g;
-        DS_CHECK(launch_dct_axis(s.res->py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, s.st));
-        DS_CHECK(launch_dct_axis(s.res->px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, s.st));
+        DS_CHECK(launch_dct_axis(s.res->py, s.w0, s.w1, g.ny, g.nx, g.ntl, 0, 0, s.st, g.py));
+        DS_CHECK(launch_dct_axis(s.res->px, s.w1, s.w0, g.ny, g.nx, g.ntl, 1, 0, s.st, g.py));
     }
     bool tri = multi() && tri_tsolve && world <= DS_MAX_WORLD;
     for (auto &s : slabs) tri = tri && s.g.ntl <= TRI_EXTRA;
@@ -1120,7 +1153,17 @@ int Solver::poisson_all() {
     FOR_SLABS(s) {
         double *p = multi() ? s.pencil : s.w0;
         double *p2 = multi() ? s.pencil2 : s.w1;
-        if (tp2) {
+        if (!multi()) {
+            // the single slab: rows may be pitched (common.h), the (y, x) columns of a layer are ny lines in each of nx rows
+            const Grid &g = s.g;
+            if (tp2) {
+                DS_CHECK(launch_dct_t_solve(s.res->pt, p, p, ny, ny * nx, 0, ny * nx, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st, g.py));
+            } else {
+                DS_CHECK(launch_dct_axis(s.res->pt, p, p2, g.ny, g.nx, nt, 2, 0, s.st, g.py));
+                DS_CHECK(launch_spectral_divide(p2, ny, nx, nt, 0, nx, D * D, s.res->cy, s.res->cx, s.res->ct, s.st, g.py));
+                DS_CHECK(launch_dct_axis(s.res->pt, p2, p, g.ny, g.nx, nt, 2, 1, s.st, g.py));
+            }
+        } else if (tp2) {
             DS_CHECK(launch_dct_t_solve(s.res->pt, p, p, ny, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
         } else {
             DS_CHECK(launch_dct_axis(s.res->pt, p, p2, s.nl, 1, nt, 2, 0, s.st));
@@ -1136,8 +1179,8 @@ int Solver::poisson_all() {
     }
     FOR_SLABS(s) {
         const Grid &g = s.g;
-        DS_CHECK(launch_dct_axis(s.res->px, s.w0, s.w1, g.ny, g.nx, g.ntl, 1, 1, s.st));
-        DS_CHECK(launch_dct_axis(s.res->py, s.w1, s.phi, g.ny, g.nx, g.ntl, 0, 1, s.st));
+        DS_CHECK(launch_dct_axis(s.res->px, s.w0, s.w1, g.ny, g.nx, g.ntl, 1, 1, s.st, g.py));
+        DS_CHECK(launch_dct_axis(s.res->py, s.w1, s.phi, g.ny, g.nx, g.ntl, 0, 1, s.st, g.py));
     }
     return 0;
 }

@@ -17,7 +17,9 @@ int Solver::recover_outputs(const double *rho0, const double *rho1, double *rho,
     DS_ARG(rho == nullptr || (rho0 != nullptr && rho1 != nullptr), "rho needs rho0 and rho1");
     cur_dev = -1;
     DS_CHECK(use_dev(device));
-    const i64 plane = ny * nx;
+    const i64 plane = slabs[0].g.plane;                    // device layers (pitched rows, common.h)
+    const i64 hplane = ny * nx;                            // host layers (reference layout)
+    const i64 py = slabs[0].g.py;
     const double cD = cScale * D, dD = dScale / D;         // recoverOrgVar (solver_dotsocp2d.m:368-386)
     if (rho && multi()) {
         FOR_SLABS(s)
@@ -31,14 +33,13 @@ int Solver::recover_outputs(const double *rho0, const double *rho1, double *rho,
             const Grid &g = s.g;
             double *d_r0 = s.w1, *d_r1 = s.w1 + plane;     // w1 holds at least two layers (nt >= 2 per slab)
             if (which == 0) {
-                if (g.first) DS_HIP(hipMemcpyAsync(d_r0, rho0, sizeof(double) * plane, hipMemcpyHostToDevice, s.st));
-                if (g.last) DS_HIP(hipMemcpyAsync(d_r1, rho1, sizeof(double) * plane, hipMemcpyHostToDevice, s.st));
+                if (g.first) DS_CHECK(copy_rows(d_r0, const_cast<double *>(rho0), ny, py, nx, true, s.st));
+                if (g.last) DS_CHECK(copy_rows(d_r1, const_cast<double *>(rho1), ny, py, nx, true, s.st));
             }
             const i64 layers = (which >= 3) ? g.ncl : g.ntl;
             DS_CHECK(launch_outputs(g, s.q, s.alpha, s.weight, d_r0, d_r1, s.a0_prev, sigma, cD, dD, which, s.w0, s.st));
-            double *h = outs[which] + (remote() ? 0 : plane * g.t0);
-            if (layers > 0)
-                DS_HIP(hipMemcpyAsync(h, s.w0, sizeof(double) * (size_t)(plane * layers), hipMemcpyDeviceToHost, s.st));
+            double *h = outs[which] + (remote() ? 0 : hplane * g.t0);
+            if (layers > 0) DS_CHECK(copy_rows(s.w0, h, ny, py, nx * layers, false, s.st));
         }
         DS_CHECK(sync_all());                               // w0 is reused by the next output
     }
@@ -68,7 +69,7 @@ int Solver::jump_from(Solver &coarse) {
     cur_dev = -1;
     cScale = prob.cScale; dScale = prob.dScale; D = prob.D; E = prob.E;
     update_coef();
-    const i64 planec = coarse.ny * coarse.nx;
+    const i64 planec = coarse.slabs[0].g.plane;           // coarse layers as they are stored (pitched rows, common.h)
     // dst (on fine slab f) <- src (on coarse slab c); the coarse level is idle, so ordering on f's stream suffices
     auto pull = [&](Slab &f, double *dst, const Slab &c, const double *src, i64 count) -> int {
         if (count <= 0) return 0;
@@ -138,7 +139,7 @@ int Solver::jump_from(Solver &coarse) {
     // q = (D_f/dScale_f) * grad(phiR) ./ w : the D_f / h factors are those of the loop's own stencil; the forward time
     // difference of a slab's last cell layer reads the first phi layer of its right neighbour
     if (multi())
-        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
+        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, slabs[0].g.plane));
     FOR_SLABS(f) {
         DS_CHECK(launch_grad(f.g, lc, f.phi, f.q, f.st));
         DS_CHECK(scale_owned(f, f.q, 1.0, false));

@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs(RhsArgs a, double *__res
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
     if (y >= a.g.ny || x >= a.g.nx) return;
-    rhs[y + a.g.ny * (x + a.g.nx * tl)] = rhs_value<WEIGHTED>(a, y, x, tl);
+    rhs[y + a.g.py * (x + a.g.nx * tl)] = rhs_value<WEIGHTED>(a, y, x, tl);
 }
 
 int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *alpha, const double *cvec,
@@ -47,8 +47,8 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_u0_tail(Grid g, const double
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     if (y >= g.ny || x >= g.nx) return;
-    const i64 k = y + g.ny * (x + g.nx * (g.ncl - 1));
-    out[y + g.ny * x] = WEIGHTED ? weight[k] * q[k] - alpha[k] : q[k] - alpha[k];
+    const i64 k = y + g.py * (x + g.nx * (g.ncl - 1));
+    out[y + g.py * x] = WEIGHTED ? weight[k] * q[k] - alpha[k] : q[k] - alpha[k];
 }
 
 int launch_u0_tail(const Grid &g, const double *q, const double *alpha, const double *weight, double *out,
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep(Grid g, LoopCoef c, co
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
     WSum W{z, beta, g.Nz};
-    const i64 node = y + g.ny * (x + g.nx * tl);
+    const i64 node = y + g.py * (x + g.nx * tl);
     if (SEG == 0) {
         if (y >= g.ny || x >= g.nx) return;
         double tmp = (-c.at) * phi[node];
@@ -128,15 +128,15 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep(Grid g, LoopCoef c, co
         if (SEG == 1) {
             if (y >= g.ny || x >= g.nx - 1) return;
             double tmp = (-c.ax) * phi[node];
-            tmp += c.ax * phi[node + g.ny];
+            tmp += c.ax * phi[node + g.py];
             const double q2 = c.sf * gather_bx(g, W, y, x, tl, tail_bx);
-            q_update<WEIGHTED>(c, tmp, q2, dc, di, g.offBx + g.bxLayer * tl + y + g.ny * x, weight, q, alpha);
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, g.offBx + g.bxLayer * tl + y + g.py * x, weight, q, alpha);
         } else {
             if (y >= g.ny - 1 || x >= g.nx) return;
             double tmp = (-c.ay) * phi[node];
             tmp += c.ay * phi[node + 1];
             const double q2 = c.sf * gather_by(g, W, y, x, tl, tail_by);
-            q_update<WEIGHTED>(c, tmp, q2, dc, di, g.offBy + g.byLayer * tl + y + (g.ny - 1) * x, weight, q, alpha);
+            q_update<WEIGHTED>(c, tmp, q2, dc, di, g.offBy + g.byLayer * tl + y + g.pyb * x, weight, q, alpha);
         }
     }
 }
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
-    const i64 node = y + g.ny * (x + g.nx * tl);
+    const i64 node = y + g.py * (x + g.nx * tl);
     if (SEG == 3) {
         // one launch for all three kinds of entries: the thread of node (y, x, tl) owns the q0 entry of
         // the cell that starts there and the bx / by edges that leave it; phi(node) is loaded once
@@ -197,21 +197,21 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
         const double dc = tbnd ? c.c2 : c.c1;
         const double di = tbnd ? c.dinv2 : c.dinv1;
         if (x < g.nx - 1) {
-            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
             double tmp = (-c.ax) * p0;
-            tmp += c.ax * phi[node + g.ny];
+            tmp += c.ax * phi[node + g.py];
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
-            if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];
+            if (tl == 0 && !g.first) q2 += tail_bx[y + g.py * x];
             q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
         if (y < g.ny - 1) {
-            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            const i64 e = g.offBy + g.byLayer * tl + y + g.pyb * x;
             double tmp = (-c.ay) * p0;
             tmp += c.ay * phi[node + 1];
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
-            if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
+            if (tl == 0 && !g.first) q2 += tail_by[y + g.pyb * x];
             q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
     } else if (SEG == 0) {
@@ -225,21 +225,21 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep_fused(Grid g, LoopCoef
         const double di = tbnd ? c.dinv2 : c.dinv1;
         if (SEG == 1) {
             if (y >= g.ny || x >= g.nx - 1) return;
-            const i64 e = g.offBx + g.bxLayer * tl + y + g.ny * x;
+            const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
             double tmp = (-c.ax) * phi[node];
-            tmp += c.ax * phi[node + g.ny];
+            tmp += c.ax * phi[node + g.py];
             double q2 = q2v[e];
             if ((x % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
-            if (tl == 0 && !g.first) q2 += tail_bx[y + g.ny * x];      // left slab's part, already times sf
+            if (tl == 0 && !g.first) q2 += tail_bx[y + g.py * x];      // left slab's part, already times sf
             q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         } else {
             if (y >= g.ny - 1 || x >= g.nx) return;
-            const i64 e = g.offBy + g.byLayer * tl + y + (g.ny - 1) * x;
+            const i64 e = g.offBy + g.byLayer * tl + y + g.pyb * x;
             double tmp = (-c.ay) * phi[node];
             tmp += c.ay * phi[node + 1];
             double q2 = q2v[e];
             if ((y & 63) == 63) q2 = c.sf * (q2 + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
-            if (tl == 0 && !g.first) q2 += tail_by[y + (g.ny - 1) * x];
+            if (tl == 0 && !g.first) q2 += tail_by[y + g.pyb * x];
             q_update<WEIGHTED, VAR>(c, tmp, q2, dc, di, e, weight, q, alpha, alpha_in);
         }
     }
@@ -440,12 +440,12 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
     const bool hasBx0 = inb && (x < g.nx - 1), hasBy0 = inb && (y < g.ny - 1);
     const bool rightCol = hasBx0 && (xl == QTX - 1), topRow = hasBy0 && (lane == TILE_Y - 1);
     if (inb) {
-        const i64 node0 = y + g.ny * (x + g.nx * t0);
+        const i64 node0 = y + g.py * (x + g.nx * t0);
         p0 = a.phi[node0];
         // halo strips of the chunk's first layer
         double hx = 0.0, hl = 0.0, hy = 0.0, hb = 0.0;
-        if (rightCol) hx = a.phi[node0 + g.ny];
-        if (xl == 0 && x >= 1) hl = a.phi[node0 - g.ny];
+        if (rightCol) hx = a.phi[node0 + g.py];
+        if (xl == 0 && x >= 1) hl = a.phi[node0 - g.py];
         if (topRow) hy = a.phi[node0 + 1];
         if (lane == 0 && y >= 1) hb = a.phi[node0 - 1];
         ph[0][xl + 1][lane + 1] = p0;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
     int par = 0;
     __syncthreads();                                              // ph[0] is complete
     for (i64 tl = t0; tl < t1; ++tl) {
-        const i64 node = yc + g.ny * (xc + g.nx * tl);
+        const i64 node = yc + g.py * (xc + g.nx * tl);
         const bool tbnd = (g.t0 + tl == 0) || (g.t0 + tl == g.nt - 1);
         const double dc = tbnd ? c.c2 : c.c1;
         const double di = tbnd ? c.dinv2 : c.dinv1;
@@ -489,14 +489,14 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
         // k_kkt after the exchange; the q0 entries of that layer need no neighbour and stay here
         const bool lay0 = KKT && tails;
         // ---------------- loads ----------------
-        const i64 eX = hasBx ? g.offBx + g.bxLayer * tl + yc + g.ny * xc : node;
-        const i64 eY = hasBy ? g.offBy + g.byLayer * tl + yc + (g.ny - 1) * xc : node;
+        const i64 eX = hasBx ? g.offBx + g.bxLayer * tl + yc + g.py * xc : node;
+        const i64 eY = hasBy ? g.offBy + g.byLayer * tl + yc + g.pyb * xc : node;
         const i64 k0 = hasCell ? node : 0;                       // q0 entries exist for tl < ncl only
         const i64 nodeT = hasCell ? node + g.plane : node;       // the layer of the next step (this one again at the end)
         const double pTl = a.phi[nodeT];
         double hx = 0.0, hl = 0.0, hy = 0.0, hb = 0.0;           // its halo strips
-        if (rightCol) hx = a.phi[nodeT + g.ny];
-        if (leftTile) hl = a.phi[nodeT - g.ny];
+        if (rightCol) hx = a.phi[nodeT + g.py];
+        if (leftTile) hl = a.phi[nodeT - g.py];
         if (topRow) hy = a.phi[nodeT + 1];
         if (belowTile) hb = a.phi[nodeT - 1];
         const double pXl = ph[par][xl + 2][lane + 1];
@@ -511,31 +511,31 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
         const double syv = a.sy[syOwn ? (tl * g.nx + x) * fg.nyblk + (y / 64 + 1) : 0];
         double tXv = 0.0, tYv = 0.0;
         if (tails) {
-            if (hasBx) tXv = a.tail_bx[y + g.ny * x];
-            if (hasBy) tYv = a.tail_by[y + (g.ny - 1) * x];
+            if (hasBx) tXv = a.tail_bx[y + g.py * x];
+            if (hasBy) tYv = a.tail_by[y + g.pyb * x];
         }
         // neighbour tiles' edges (first column / first row of the tile)
         double pLl = 0.0, alL = 0.0, gL = 0.0, wL = 1.0, sxL = 0.0, tLv = 0.0;
         i64 eL = 0;
         if (leftTile) {
-            eL = g.offBx + g.bxLayer * tl + y + g.ny * (x - 1);
+            eL = g.offBx + g.bxLayer * tl + y + g.py * (x - 1);
             pLl = ph[par][0][lane + 1];
             alL = a.alpha_in[eL];
             gL = a.q2v[eL];
             if (WEIGHTED) wL = a.weight[eL];
             if (((x - 1) % fg.XB) == fg.XB - 1) sxL = a.sx[(tl * fg.nxblk + ((x - 1) / fg.XB + 1)) * g.ny + y];
-            if (tails) tLv = a.tail_bx[y + g.ny * (x - 1)];
+            if (tails) tLv = a.tail_bx[y + g.py * (x - 1)];
         }
         double pBl = 0.0, alB = 0.0, gB = 0.0, wB = 1.0, syB = 0.0, tBv = 0.0;
         i64 eB = 0;
         if (belowTile) {
-            eB = g.offBy + g.byLayer * tl + (y - 1) + (g.ny - 1) * x;
+            eB = g.offBy + g.byLayer * tl + (y - 1) + g.pyb * x;
             pBl = ph[par][xl + 1][0];
             alB = a.alpha_in[eB];
             gB = a.q2v[eB];
             if (WEIGHTED) wB = a.weight[eB];
             if (((y - 1) & 63) == 63) syB = a.sy[(tl * g.nx + x) * fg.nyblk + ((y - 1) / 64 + 1)];
-            if (tails) tBv = a.tail_by[(y - 1) + (g.ny - 1) * x];
+            if (tails) tBv = a.tail_by[(y - 1) + g.pyb * x];
         }
         // ---------------- arithmetic ----------------
         // the adjoint sums of an edge on a tile border are completed from the neighbour tile's partial (k_qstep_fused)
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
         // ---------------- stores ----------------
         if (hasCell) {
             put(node, q0n, a0n, ain0);
-            if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.ny * x] = u0;
+            if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.py * x] = u0;
         }
         if (hasBx) put(eX, qXn, aXn, ainX);
         if (hasBy) put(eY, qYn, aYn, ainY);
@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs_fixup(Grid g, double at,
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     if (y >= g.ny || x >= g.nx) return;
-    const i64 i = y + g.ny * x;
+    const i64 i = y + g.py * x;
     rhs[i] = rhs[i] + at * u0_prev[i];
 }
 
@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_grad(Grid g, LoopCoef c, con
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
     if (y >= g.ny || x >= g.nx) return;
-    const i64 node = y + g.ny * (x + g.nx * tl);
+    const i64 node = y + g.py * (x + g.nx * tl);
     const double p0 = phi[node];
     if (tl < g.ncl) {
         double tmp = (-c.at) * p0;
@@ -883,13 +883,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_grad(Grid g, LoopCoef c, con
     }
     if (x < g.nx - 1) {
         double tmp = (-c.ax) * p0;
-        tmp += c.ax * phi[node + g.ny];
-        out[g.offBx + g.bxLayer * tl + y + g.ny * x] = tmp;
+        tmp += c.ax * phi[node + g.py];
+        out[g.offBx + g.bxLayer * tl + y + g.py * x] = tmp;
     }
     if (y < g.ny - 1) {
         double tmp = (-c.ay) * p0;
         tmp += c.ay * phi[node + 1];
-        out[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x] = tmp;
+        out[g.offBy + g.byLayer * tl + y + g.pyb * x] = tmp;
     }
 }
 
@@ -912,14 +912,14 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_tail_finalize(Grid g, LoopCo
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = g.ncl;
     if (y < g.ny && x < g.nx - 1) {
-        double v = q2v[g.offBx + g.bxLayer * tl + y + g.ny * x];
+        double v = q2v[g.offBx + g.bxLayer * tl + y + g.py * x];
         if ((x % fg.XB) == fg.XB - 1) v = c.sf * (v + sx[(tl * fg.nxblk + (x / fg.XB + 1)) * g.ny + y]);
-        tail_bx[y + g.ny * x] = v;
+        tail_bx[y + g.py * x] = v;
     }
     if (y < g.ny - 1 && x < g.nx) {
-        double v = q2v[g.offBy + g.byLayer * tl + y + (g.ny - 1) * x];
+        double v = q2v[g.offBy + g.byLayer * tl + y + g.pyb * x];
         if ((y & 63) == 63) v = c.sf * (v + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
-        tail_by[y + (g.ny - 1) * x] = v;
+        tail_by[y + g.pyb * x] = v;
     }
 }
 
@@ -942,20 +942,20 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_tail(Grid g, const doubl
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = g.ncl - 1;
     if (y < g.ny && x < g.nx) {
-        const i64 cidx = y + g.ny * (x + g.nx * tl);
+        const i64 cidx = y + g.py * (x + g.nx * tl);
         const double a = alpha[cidx];
-        a0[y + g.ny * x] = a;
-        a0w[y + g.ny * x] = weight ? weight[cidx] * a : a;
+        a0[y + g.py * x] = a;
+        a0w[y + g.py * x] = weight ? weight[cidx] * a : a;
     }
     if (y < g.ny && x < g.nx - 1) {
-        double acc = beta[3 * g.Nz + y + g.ny * ((x + 1) + g.nx * tl)];
-        acc += beta[4 * g.Nz + y + g.ny * (x + g.nx * tl)];
-        bt_bx[y + g.ny * x] = acc;
+        double acc = beta[3 * g.Nz + y + g.py * ((x + 1) + g.nx * tl)];
+        acc += beta[4 * g.Nz + y + g.py * (x + g.nx * tl)];
+        bt_bx[y + g.py * x] = acc;
     }
     if (y < g.ny - 1 && x < g.nx) {
-        double acc = beta[7 * g.Nz + (y + 1) + g.ny * (x + g.nx * tl)];
-        acc += beta[8 * g.Nz + y + g.ny * (x + g.nx * tl)];
-        bt_by[y + (g.ny - 1) * x] = acc;
+        double acc = beta[7 * g.Nz + (y + 1) + g.py * (x + g.nx * tl)];
+        acc += beta[8 * g.Nz + y + g.py * (x + g.nx * tl)];
+        bt_by[y + g.pyb * x] = acc;
     }
 }
 

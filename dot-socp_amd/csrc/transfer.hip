@@ -29,7 +29,7 @@ __device__ __forceinline__ double interp_yx(const F &f, i64 yf, i64 xf) {
 // phi_f = sc_out * interp(sc_in * phi_c)
 // Time slabs: blockIdx.z is the slab-local fine layer, t0f + blockIdx.z the global one; `phic` holds the coarse layers
 // tc0, tc0 + 1, ... (gathered from the coarse slabs that own them).
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_phi(i64 nyf, i64 nxf, i64 t0f, i64 tc0, i64 nyc, i64 nxc,
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_phi(i64 nyf, i64 nxf, i64 pyf, i64 t0f, i64 tc0, i64 pyc, i64 nxc,
                                                                  const double *__restrict__ phic,
                                                                  double *__restrict__ phif, double sc_in,
                                                                  double sc_out) {
@@ -37,21 +37,21 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_phi(i64 nyf, i64 nxf
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tloc = blockIdx.z, t = t0f + tloc;
     if (y >= nyf || x >= nxf) return;
-    const i64 planec = nyc * nxc;
+    const i64 planec = pyc * nxc;                 // pyf, pyc: row pitches of the fine / coarse arrays (common.h)
     const i64 tc = (t >> 1) - tc0;
     auto layer = [&](i64 tt) {
         const double *p = phic + planec * tt;
-        return interp_yx([&](i64 yc, i64 xc) { return sc_in * p[yc + nyc * xc]; }, y, x);
+        return interp_yx([&](i64 yc, i64 xc) { return sc_in * p[yc + pyc * xc]; }, y, x);
     };
     double v = layer(tc);
     if (t & 1) v = (v + layer(tc + 1)) / 2;
-    phif[y + nyf * (x + nxf * tloc)] = sc_out * v;
+    phif[y + pyf * (x + nxf * tloc)] = sc_out * v;
 }
 
 // per cone column: betaR = interp(sc_in1 * (sc_in0 * beta_c)) ; beta_f = sc_out * betaR ; neg = -betaR
 // (time slabs as in k_prolong_phi: t0f = global index of the slab's first fine cell, `betac` holds the coarse cell
 // layers tc0, tc0 + 1, ... of every cone column, Nzc doubles per column)
-__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_beta(i64 nyf, i64 nxf, i64 t0f, i64 tc0, i64 nyc, i64 nxc, i64 Nzc,
+__global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_beta(i64 nyf, i64 nxf, i64 pyf, i64 t0f, i64 tc0, i64 pyc, i64 nxc, i64 Nzc,
                                                                   i64 Nzf, const double *__restrict__ betac,
                                                                   double *__restrict__ betaf, double *__restrict__ neg,
                                                                   double sc_in0, double sc_in1, double sc_out) {
@@ -60,11 +60,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_prolong_beta(i64 nyf, i64 nx
     const i64 tloc = blockIdx.z;              // slab-local fine cell
     if (y >= nyf || x >= nxf) return;
     const i64 tc = ((t0f + tloc) >> 1) - tc0; // interpolate.m:73-84: fR(:, :, oddT) = fR(:, :, evenT) = f
-    const i64 i = y + nyf * (x + nxf * tloc);
+    const i64 i = y + pyf * (x + nxf * tloc);
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
-        const double *p = betac + j * Nzc + nyc * nxc * tc;
-        const double v = interp_yx([&](i64 yc, i64 xc) { return sc_in1 * (sc_in0 * p[yc + nyc * xc]); }, y, x);
+        const double *p = betac + j * Nzc + pyc * nxc * tc;
+        const double v = interp_yx([&](i64 yc, i64 xc) { return sc_in1 * (sc_in0 * p[yc + pyc * xc]); }, y, x);
         betaf[j * Nzf + i] = sc_out * v;
         neg[j * Nzf + i] = -v;
     }
@@ -83,7 +83,7 @@ int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, doubl
                        hipStream_t st, i64 tc0) {
     if (gf.ntl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ntl);
-    hipLaunchKernelGGL(k_prolong_phi, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.t0, tc0, gc.ny, gc.nx, phic, phif,
+    hipLaunchKernelGGL(k_prolong_phi, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx, phic, phif,
                        sc_in, sc_out);
     DS_HIP(hipGetLastError());
     return 0;
@@ -93,8 +93,19 @@ int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, dou
                         double sc_in1, double sc_out, hipStream_t st, i64 tc0, i64 Nzc) {
     if (gf.ncl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ncl);
-    hipLaunchKernelGGL(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.t0, tc0, gc.ny, gc.nx,
+    hipLaunchKernelGGL(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx,
                        Nzc < 0 ? gc.Nz : Nzc, gf.Nz, betac, betaf, neg, sc_in0, sc_in1, sc_out);
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) k_fill(double *__restrict__ x, i64 n, double v) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) x[i] = v;
+}
+
+int launch_fill(double *x, i64 n, double v, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_fill, dim3(launch_blocks(n, 256, 1 << 16)), dim3(256), 0, st, x, n, v);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -134,22 +145,22 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_outputs(Grid g, OutArgs a, i
         return a.weight ? a.weight[k] * v : v;
     };
     auto B = [&](i64 k) { return a.dD * a.q[k]; };
-    const i64 node = y + g.ny * (x + g.nx * t);
+    const i64 node = y + g.py * (x + g.nx * t);
     double r = 0.0;
     if (which == 0) {
-        if (tg == 0) r = a.rho0[y + g.ny * x];
-        else if (tg == nt - 1) r = a.rho1[y + g.ny * x];
-        else r = ((t == 0 ? a.a_prev[y + g.ny * x] : A(node - g.plane)) + A(node)) / 2;
+        if (tg == 0) r = a.rho0[y + g.py * x];
+        else if (tg == nt - 1) r = a.rho1[y + g.py * x];
+        else r = ((t == 0 ? a.a_prev[y + g.py * x] : A(node - g.plane)) + A(node)) / 2;
     } else if (which == 1 || which == 2) {
         const double f = (tg == 0 || tg == nt - 1) ? 2.0 : 1.0;
         if (which == 1) {
             if (x >= 1 && x <= g.nx - 2) {
-                const i64 e = g.offBx + g.bxLayer * t + y + g.ny * x;
-                r = (A(e - g.ny) * f + A(e) * f) / 2;
+                const i64 e = g.offBx + g.bxLayer * t + y + g.py * x;
+                r = (A(e - g.py) * f + A(e) * f) / 2;
             }
         } else {
             if (y >= 1 && y <= g.ny - 2) {
-                const i64 e = g.offBy + g.byLayer * t + y + (g.ny - 1) * x;
+                const i64 e = g.offBy + g.byLayer * t + y + g.pyb * x;
                 r = (A(e - 1) * f + A(e) * f) / 2;
             }
         }
@@ -157,14 +168,14 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_outputs(Grid g, OutArgs a, i
         r = B(node);
     } else if (which == 4) {
         if (x >= 1 && x <= g.nx - 2) {
-            const i64 e = g.offBx + g.bxLayer * t + y + g.ny * x;
-            const double m0 = (B(e - g.ny) + B(e)) / 2;
-            const double m1 = (B(e - g.ny + g.bxLayer) + B(e + g.bxLayer)) / 2;
+            const i64 e = g.offBx + g.bxLayer * t + y + g.py * x;
+            const double m0 = (B(e - g.py) + B(e)) / 2;
+            const double m1 = (B(e - g.py + g.bxLayer) + B(e + g.bxLayer)) / 2;
             r = (m0 + m1) / 2;
         }
     } else {
         if (y >= 1 && y <= g.ny - 2) {
-            const i64 e = g.offBy + g.byLayer * t + y + (g.ny - 1) * x;
+            const i64 e = g.offBy + g.byLayer * t + y + g.pyb * x;
             const double m0 = (B(e - 1) + B(e)) / 2;
             const double m1 = (B(e - 1 + g.byLayer) + B(e + g.byLayer)) / 2;
             r = (m0 + m1) / 2;
