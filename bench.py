@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+BUILD_ROUND = 3         # profiles/cone_proj_traffic.json is only quoted when it was measured on this round's build
 
 
 def parse_args():
@@ -331,15 +332,39 @@ def main():
         kname, (proj_ms, proj_n) = "k_cone_march<0> (cone projection)", times["cone_proj"]
         alg_bytes = 8.0 * (20 * Nz + Nq)
     achieved = alg_bytes / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes of the dominant kernel by the PMC counters: a figure of the builder's profiling run of THIS round's build
+    # (profiles/cone_proj_traffic.json, separate --pmc FETCH_SIZE / WRITE_SIZE passes), not of this run -- tagged as such,
+    # and left out when the record is from another round, grid, method or kernel
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "cone_proj_traffic.json")
     if os.path.exists(tf):
         try:
             rec = json.load(open(tf))
-            if rec.get("grid") == [ny, nx, nt] and args.method in ("inPALM", "ALG2"):
+            if (rec.get("grid") == [ny, nx, nt] and args.method in ("inPALM", "ALG2") and rec.get("round") == BUILD_ROUND
+                    and kname.startswith(rec.get("kernel", "?").replace(" ", "")[:14])):
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/cone_proj_traffic.json (builder's rocprofv3 PMC passes of round {rec.get('round')}, "
+                                  f"commit {rec.get('commit', 'n/a')}; not a counter of this run)")
         except Exception:
             traffic = None
+    # the other kernels of a plain iteration, so that the line shows the one furthest below the roofline; phase timers
+    # (HIP events on the launch stream) with the algorithmic bytes of DESIGN.md section 3; Nphi = nodes of this slab
+    Nphi = ny * nx * ntl
+
+    def krow(name, nbytes, key, launches_per_phase=1):
+        ms, n = times[key]
+        if ms <= 0 or n <= 0:
+            return None
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"name": name, "algorithmic_bytes": nbytes, "avg_ms": round(ms, 4), "launches_per_phase": launches_per_phase,
+                "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+    kernels = [r for r in (
+        krow(kname, alg_bytes, {"acc-ADMM": "acc_cone", "PALM": "cone_fused_a"}.get(args.method, "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_proj")),
+        krow("k_qstep_rhs (A phi, q-step, alpha update, next rhs)", 8.0 * (3 * Nphi + 4 * Nq), "qstep"),
+        krow("Poisson solve: y, x forward, fused t pass, x, y inverse (five launches; k_dct_* / k_pfa_*)", 8.0 * 10 * Nphi,
+             "poisson", 5),
+    ) if r]
     out = {
         "metric": "ADMM iters/sec on NxNxT dot2d staggered grid at 1/2/4/8 MI355X",
         "value": args.steps / dt,
@@ -357,13 +382,20 @@ def main():
                        "inPALM": "inPALM tau=1.9", "ALG2": "ALG2 tau=1.0", "PALM": "PALM tau=1.9",
                        "acc-ADMM": "acc-ADMM (Halpern, rho=2, restart=100)"}[args.method] + ", levelN=1",
                    "grid": [ny, nx, nt], "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
+                   # the timed region runs with the library's per-phase HIP events switched on (they feed roofline and
+                   # kernel_ms); DOTSOCP_BENCH_NOPROF=1 times it without them
+                   "per_phase_hip_events_in_timed_region": not bool(os.environ.get("DOTSOCP_BENCH_NOPROF")),
                    "parallelism": (f"rank share: slab {share // 2} of {share} time slabs on 1 GPU, neighbour messages as local "
                                    f"copies (timing only, not a valid solve)") if share else
                                   ("1 GPU" if world == 1 else f"{world} time slabs")},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": proj_ms, "launches": proj_n},
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_ms": proj_ms, "launches": proj_n,
+                     # SURVEY.md 8d's narrower figure for the projection alone, 8 (20 Nz + Nq): what the same launch scores
+                     # if only beta in, q in and z out are counted (this kernel also reads q^{k-1} and writes the adjoint sums)
+                     "frac_projection_only": (8.0 * (20 * Nz + Nq) / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if proj_ms > 0 else 0.0,
+                     "kernels": kernels},
         "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
     }
     if share:

@@ -262,3 +262,68 @@ def test_rccl_communicator_world1(request):
     np.testing.assert_array_equal(hist["iter"], h1["iter"])
     np.testing.assert_allclose(hist["kkt"], h1["kkt"], rtol=1e-9, atol=1e-12)
     assert _relerr(phi, ref.phi) <= 1e-11
+
+
+def test_pitched_rows_change_nothing():
+    """Single-slab contexts store rows whose length is no multiple of 16 doubles padded to the next 128-byte boundary
+    (common.h: Grid::py; the 2^k+1 grids of the multilevel driver).  Only addresses change -- tiles, summation orders and
+    the arithmetic of every kernel are the same; the one difference is WHICH two lines share a complex transform in the
+    t pass of the Poisson solve (reference layout: the ny * nx columns of a layer are paired across row ends, pitched:
+    within rows), which moves results by rounding.  So every iterate, the KKT history and the device-side outputs agree
+    with the reference layout (DOTSOCP_PITCH=0; read once per process, hence the subprocesses) to <= 1e-11 of the
+    array's largest entry, with identical KKT schedules.  Covers 2-D (ny = 65 -> 80, nx a power of two and not),
+    weighted, 1-D (129 -> 144), PALM and acc-ADMM."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np, dotsocp_amd as D\n"
+        "from oracle import driver as OD\n"
+        "from oracle.examples import get_example_2d, get_example_1d, gene_barrier_of_circle_pillar, get_weight_by_barrier, ensure_barrier_validity\n"
+        "out = {}\n"
+        "def run(tag, rho0, rho1, nt, method='inPALM', weight=None, K=40):\n"
+        "    dim = 2 if np.ndim(rho0) == 2 else 1\n"
+        "    var, model = D.initialize(rho0, rho1, nt)\n"
+        "    if weight is not None: model.weight = weight\n"
+        "    D.InitialScaling(var, model, True, None, dim=dim, weighted=weight is not None)\n"
+        "    o = OD.default_opts(dict(tol=0.0, maxit=K), method, weight is not None)\n"
+        "    ctx = D.InPALMContext(var, o, model, weighted=weight is not None, method=method)\n"
+        "    ctx.run(K); hist, sigma = ctx.finish(download=True); ctx.close()\n"
+        "    for f in ('phi', 'q', 'z', 'alpha', 'beta'): out[tag + f] = np.asarray(getattr(var, f)).copy()\n"
+        "    out[tag + 'kkt'] = np.asarray(hist['kkt']); out[tag + 'sigma'] = np.array([sigma])\n"
+        "r0, r1 = get_example_2d('example1', 65, 33)\n"
+        "run('a', r0, r1, 17)\n"
+        "r0, r1 = get_example_2d('example1', 49, 64)\n"
+        "run('b', r0, r1, 16)\n"
+        "run('p', r0, r1, 16, method='PALM', K=15)\n"
+        "run('h', r0, r1, 16, method='acc-ADMM', K=15)\n"
+        "r0, r1 = get_example_2d('example1', 33, 33)\n"
+        "bar = gene_barrier_of_circle_pillar(); w = get_weight_by_barrier(33, 33, 9, bar); r0, r1, _ = ensure_barrier_validity(r0, r1, bar)\n"
+        "run('w', r0, r1, 9, weight=w, K=20)\n"
+        "r0, r1 = get_example_1d('gaussian', 129)\n"
+        "run('d', r0, r1, 33)\n"
+        "o2, tML, hML, h = D.solver_dotsocp2d(*get_example_2d('example1', 33, 33), 17, 2, dict(tol=1e-3), 'inPALM')\n"
+        "for f in ('rho', 'Ex', 'Ey', 'q0', 'bx', 'by'): out['m' + f] = np.asarray(o2[f])\n"
+        "out['miter'] = np.asarray(h['iter'])\n"
+        "np.savez(sys.argv[1], **out)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for flag in ("0", "1"):
+            path = os.path.join(tmp, f"pitch{flag}.npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DOTSOCP_PITCH=flag), cwd=root,
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            with np.load(path) as z:
+                res[flag] = {k: z[k].copy() for k in z.files}
+    assert set(res["0"]) == set(res["1"]) and len(res["0"]) > 40
+    for k in res["0"]:
+        a, b = res["1"][k], res["0"][k]
+        if k.endswith("iter"):
+            np.testing.assert_array_equal(a, b, err_msg=k)
+        elif k.endswith("kkt") or k.endswith("sigma"):
+            np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-15, err_msg=k)
+        else:
+            scale = max(np.max(np.abs(b)), 1e-300)
+            assert np.max(np.abs(a - b)) <= 1e-11 * scale, (k, np.max(np.abs(a - b)) / scale)
