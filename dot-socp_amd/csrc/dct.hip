@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace dotsocp {
@@ -169,6 +170,27 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Twiddle tables as the kernels see them: a plain pointer, or -- for the 2048-point lines of the pipelined kernels, whose
+// two tile buffers leave 32 KB of LDS for tables -- the symmetric part only:
+//   exp(-2 pi i (j + n/4) / n) = -i exp(-2 pi i j / n)               -> a quarter of the FFT twiddles,
+//   ww[n - k] = (-imag ww[k], -real ww[k])   (0 < k < n/2)           -> half of the DCT weights (+ the entry n/2).
+struct TwQuarter {
+    const double2 *t;
+    int q;                  // n / 4 entries
+    __device__ __forceinline__ double2 operator[](int j) const {
+        const double2 v = t[j & (q - 1)];
+        return (j & q) ? make_double2(v.y, -v.x) : v;
+    }
+};
+struct WwHalf {
+    const double2 *t;
+    int h;                  // n / 2: entries 0 .. h
+    __device__ __forceinline__ double2 operator[](int m) const {
+        const double2 v = t[m <= h ? m : 2 * h - m];
+        return (m <= h) ? v : make_double2(-v.y, -v.x);
+    }
+};
+
 // d * exp(-2 pi i t / 16), t in [0, 8): the constant part of the twiddles inside a register group
 __device__ __forceinline__ double2 mul_w16(double2 d, int t) {
     const double h = 0.70710678118654752440;   // cos(pi/4)
@@ -192,9 +214,8 @@ __device__ __forceinline__ double2 mul_w16(double2 d, int t) {
 // textbook in-place radix-2 DIF, so the output order is plain bit reversal).
 // LES > 0: the rows of a tile are interleaved element by element (element p of row r at (padi(p) << LES) + r, `row`
 // = tile + r) -- the image an LDS-DMA piece leaves when each lane fetches one (pair, k) element; LES = 0: plain rows
-template <int LR, int LES = 0>
-__device__ __forceinline__ void dif_group(double2 *__restrict__ row, int sl, int bidx, int lg,
-                                          const double2 *__restrict__ tw) {
+template <int LR, int LES = 0, class TW = const double2 *>
+__device__ __forceinline__ void dif_group(double2 *__restrict__ row, int sl, int bidx, int lg, TW tw) {
     constexpr int R = 1 << LR;
     const int strideLog = sl - LR;
     const int j = bidx & ((1 << strideLog) - 1);
@@ -252,9 +273,8 @@ __device__ __forceinline__ void fft_rows_wave(double2 *rows, int lrw, int lg, in
 // Decimation-in-time twin of dif_group: same element set (base + m * S/R), the butterflies of spans S/2^(LR-1),
 // ..., S/2, S in INCREASING order with the twiddle applied before the add / subtract -- bit-reversed input,
 // natural-order output.  Used where the spectrum is needed in place in natural order (fused t-axis solve).
-template <int LR, int LES = 0>
-__device__ __forceinline__ void dit_group(double2 *__restrict__ row, int sl, int bidx, int lg,
-                                          const double2 *__restrict__ tw) {
+template <int LR, int LES = 0, class TW = const double2 *>
+__device__ __forceinline__ void dit_group(double2 *__restrict__ row, int sl, int bidx, int lg, TW tw) {
     constexpr int R = 1 << LR;
     const int strideLog = sl - LR;
     const int j = bidx & ((1 << strideLog) - 1);
@@ -350,9 +370,8 @@ __device__ __forceinline__ void idct_combine_wave(double2 *rows, int lrw, int lg
 
 // (Xa[k], Xb[k]) = real(ww[k] * V_{a,b}[k]) from the bit-reversed FFT of va + i vb:
 // V_a = (V[k] + conj(V[n-k])) / 2, V_b = (V[k] - conj(V[n-k])) / (2i)   (mirt_dctn.m:130)
-template <int LES = 0>
-__device__ __forceinline__ double2 dct_post(const double2 *__restrict__ r, int k, int n, int lg,
-                                            const double2 *__restrict__ ww) {
+template <int LES = 0, class WW = const double2 *>
+__device__ __forceinline__ double2 dct_post(const double2 *__restrict__ r, int k, int n, int lg, WW ww) {
     const double2 vk = r[padi(bitrev(k, lg)) << LES];
     const double2 vm = r[padi(bitrev((n - k) & (n - 1), lg)) << LES];
     const double2 w = ww[k];
@@ -621,9 +640,8 @@ __device__ __forceinline__ void fft_rows_wg(double2 *rows, int lrows, int lg, in
     }
 }
 
-template <bool RAWB = false>
-__device__ __forceinline__ void idct_combine_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T,
-                                                const double2 *__restrict__ ww) {
+template <bool RAWB = false, class WW = const double2 *>
+__device__ __forceinline__ void idct_combine_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T, WW ww) {
     const int n = 1 << lg, lh = lg - 1;
     const int total = 1 << (lrows + lh);
     for (int b = t; b < total; b += T) {
@@ -712,7 +730,7 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pipelined flavour (axis 0, n = 128 .. 1024).  What limits the kernels above is not a unit but the bytes in flight:
+// Pipelined flavour (axis 0, n = 128 .. 2048).  What limits the kernels above is not a unit but the bytes in flight:
 // while a workgroup computes, its tile sits in LDS and nothing of it travels, and the LDS holds two tiles only (the
 // same kernels with the transform skipped run at the copy rate; the transform's time adds in full).  Here ONE
 // persistent workgroup of 512 threads per CU (two waves per SIMD, 256 registers each) walks tiles of 8192 doubles
@@ -755,8 +773,8 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
 // the register groups of fft_rows_wg for a length known at compile time (same plan, same arithmetic)
 // the same register groups on a pair-interleaved tile (dif_group<., LES>): item b = (row b % rows, group b / rows), so the
 // lanes of a wave sweep the rows of one element first -- consecutive LDS addresses
-template <int LG, int LROWS, int T, int ST = 0, int SL = LG>
-__device__ __forceinline__ void fft_tile_pipe(double2 *tile, int t, const double2 *__restrict__ tw) {
+template <int LG, int LROWS, int T, int ST = 0, int SL = LG, class TW = const double2 *>
+__device__ __forceinline__ void fft_tile_pipe(double2 *tile, int t, TW tw) {
     constexpr int NST = (LG + 3) >> 2;
     constexpr int BASEB = LG / NST, EXTRA = LG % NST;
     if constexpr (ST < NST) {
@@ -789,8 +807,8 @@ __device__ __forceinline__ void fft_tile_pipe_dit(double2 *tile, int t, const do
 }
 
 // inverse pre-processing (idct_combine_wg) on a pair-interleaved tile
-template <int LG, int LROWS, int T>
-__device__ __forceinline__ void idct_combine_tile(double2 *tile, int t, const double2 *__restrict__ ww) {
+template <int LG, int LROWS, int T, class WW = const double2 *>
+__device__ __forceinline__ void idct_combine_tile(double2 *tile, int t, WW ww) {
     constexpr int n = 1 << LG, lh = LG - 1;
     constexpr int TOTAL = 1 << (LROWS + lh);
 #pragma unroll
@@ -817,8 +835,8 @@ __device__ __forceinline__ void idct_combine_tile(double2 *tile, int t, const do
     lds_barrier();
 }
 
-template <int LG, int LROWS, int T, int RS, int ST = 0, int SL = LG>
-__device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, const double2 *__restrict__ tw) {
+template <int LG, int LROWS, int T, int RS, int ST = 0, int SL = LG, class TW = const double2 *>
+__device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, TW tw) {
     constexpr int NST = (LG + 3) >> 2;
     constexpr int BASEB = LG / NST, EXTRA = LG % NST;
     if constexpr (ST < NST) {
@@ -841,11 +859,17 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
     constexpr int RS = n + 1;                         // odd row stride: rows start on different banks
     constexpr int lrows = PIPE_LG_CPLX - LG;          // 2^lrows rows (pairs of lines) per tile
     constexpr int BUF = RS << lrows;                  // complex elements per buffer
-    double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
+    // 2048-point lines: only the symmetric part of the tables fits beside the two buffers (TwQuarter, WwHalf)
+    constexpr bool BIG = LG > 10;
+    constexpr int NTW = BIG ? (n >> 2) : (n >> 1), NWW = BIG ? (n >> 1) + 1 : n;
+    double2 *twS = lds + 2 * BUF, *wwS = twS + NTW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < (n >> 1); i += PIPE_THREADS) twS[i] = tw[i];
-    for (int i = tid; i < n; i += PIPE_THREADS) wwS[i] = ww[i];
+    for (int i = tid; i < NTW; i += PIPE_THREADS) twS[i] = tw[i];
+    for (int i = tid; i < NWW; i += PIPE_THREADS) wwS[i] = ww[i];
+    typename std::conditional<BIG, TwQuarter, const double2 *>::type twA;
+    typename std::conditional<BIG, WwHalf, const double2 *>::type wwA;
+    if constexpr (BIG) { twA = TwQuarter{twS, n >> 2}; wwA = WwHalf{wwS, n >> 1}; } else { twA = twS; wwA = wwS; }
     const unsigned ldsBase = (unsigned)(uintptr_t)lds;
     auto dma = [&](int tile, int b) {
         const char *g = (const char *)(src + ((i64)tile << (PIPE_LG_CPLX + 1))) + (wave * PIPE_ND) * 1024 + lane * 16;
@@ -862,9 +886,9 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
     if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIPE_ND) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    // items of the staging / store loops: (row, j < n / 2), four per thread
-    const int rr0 = tid >> lh, j0 = tid & ((1 << lh) - 1);
-    constexpr int DRR = PIPE_THREADS >> lh;          // row step of the second item
+    // items of the staging / store loops: (row, j < n / 2) = (b >> lh, b & (n / 2 - 1)) for b = tid + u * threads, four per thread
+    auto item_row = [&](int u) { return (tid + u * PIPE_THREADS) >> lh; };
+    auto item_j = [&](int u) { return (tid + u * PIPE_THREADS) & ((1 << lh) - 1); };
     for (int it = 0; tile < nTiles; tile += stride, ++it) {
         const int b = it & 1;
         double2 *buf = lds + b * BUF;
@@ -874,14 +898,15 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
             double2 A[PIPE_IT], B[PIPE_IT];
 #pragma unroll
             for (int u = 0; u < PIPE_IT; ++u) {
-                const int rr = rr0 + u * DRR;
+                const int rr = item_row(u), j0 = item_j(u);
                 A[u] = *(const double2 *)(raw + (2 * rr) * n + 2 * j0);
                 B[u] = *(const double2 *)(raw + (2 * rr + 1) * n + 2 * j0);
             }
             lds_barrier();
 #pragma unroll
             for (int u = 0; u < PIPE_IT; ++u) {
-                double2 *r = buf + (rr0 + u * DRR) * RS;
+                double2 *r = buf + item_row(u) * RS;
+                const int j0 = item_j(u);
                 if (!INVERSE) {
                     r[padi(j0)] = make_double2(A[u].x, B[u].x);
                     r[padi(n - 1 - j0)] = make_double2(A[u].y, B[u].y);
@@ -892,16 +917,16 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
             }
         }
         lds_barrier();
-        if (INVERSE) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwS);
-        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twS);
+        if (INVERSE) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwA);
+        fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twA);
         double *out = dst + ((i64)tile << (PIPE_LG_CPLX + 1));
 #pragma unroll
         for (int u = 0; u < PIPE_IT; ++u) {
-            const int rr = rr0 + u * DRR;
+            const int rr = item_row(u), j0 = item_j(u);
             const double2 *r = buf + rr * RS;
             double2 Av, Bv;
             if (!INVERSE) {
-                const double2 p0 = dct_post(r, 2 * j0, n, LG, wwS), p1 = dct_post(r, 2 * j0 + 1, n, LG, wwS);
+                const double2 p0 = dct_post(r, 2 * j0, n, LG, wwA), p1 = dct_post(r, 2 * j0 + 1, n, LG, wwA);
                 Av = make_double2(p0.x, p1.x);
                 Bv = make_double2(p0.y, p1.y);
             } else {
@@ -937,11 +962,16 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
     constexpr int lrows = PIPE_LG_CPLX - LG;          // log2(pairs per tile)
     constexpr int NP = 1 << lrows;
     constexpr int BUF = 1 << PIPE_LG_CPLX;            // complex elements per buffer (no padding: the swizzle permutes)
-    double2 *twS = lds + 2 * BUF, *wwS = twS + (n >> 1);
+    constexpr bool BIG = LG > 10;                     // 2048-point lines: symmetric part of the tables only (see k_dct_axis0_pipe)
+    constexpr int NTW = BIG ? (n >> 2) : (n >> 1), NWW = BIG ? (n >> 1) + 1 : n;
+    double2 *twS = lds + 2 * BUF, *wwS = twS + NTW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < (n >> 1); i += PIPE_THREADS) twS[i] = tw[i];
-    for (int i = tid; i < n; i += PIPE_THREADS) wwS[i] = ww[i];
+    for (int i = tid; i < NTW; i += PIPE_THREADS) twS[i] = tw[i];
+    for (int i = tid; i < NWW; i += PIPE_THREADS) wwS[i] = ww[i];
+    typename std::conditional<BIG, TwQuarter, const double2 *>::type twA;
+    typename std::conditional<BIG, WwHalf, const double2 *>::type wwA;
+    if constexpr (BIG) { twA = TwQuarter{twS, n >> 2}; wwA = WwHalf{wwS, n >> 1}; } else { twA = twS; wwA = wwS; }
     const unsigned ldsBase = (unsigned)(uintptr_t)lds;
     // element offset of a tile's first line (the 2 NP lines of a tile are consecutive in memory: nin % (2 NP) == 0)
     auto tile_base = [&](int tile) { return map.base((i64)tile << (lrows + 1)); };
@@ -956,9 +986,11 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
             glds16(g0 + (i64)k * map.nin, l0 + (unsigned)c * 1024u);
         }
     };
-    // tile order: workgroup w runs on XCD w % 8; the tiles 2p and 2p + 1 go to two workgroups of one XCD
-    const int w = blockIdx.x, stride = gridDim.x;     // gridDim.x is a multiple of 16
-    int tile = ((((w >> 4) << 3) + (w & 7)) << 1) | ((w >> 3) & 1);
+    // tile order: workgroup w runs on XCD w % 8; the tiles 2p and 2p + 1 (n = 2048, tiles 32 bytes wide: 4p .. 4p + 3) that
+    // share every 128-byte line go to workgroups of one XCD at the same time
+    const int w = blockIdx.x, stride = gridDim.x;     // gridDim.x is a multiple of 32
+    int tile = BIG ? (((((w >> 5) << 3) + (w & 7)) << 2) | ((w >> 3) & 3))
+                   : (((((w >> 4) << 3) + (w & 7)) << 1) | ((w >> 3) & 1));
     if (tile < nTiles) dma(tile, 0);
     if (tile + stride < nTiles) dma(tile + stride, 1);
     // the first tile has landed when only the second one's DMA is outstanding (vector-memory operations of a wave
@@ -969,8 +1001,8 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
     for (int it = 0; tile < nTiles; tile += stride, ++it) {
         const int b = it & 1;
         double2 *buf = lds + b * BUF;
-        if (MODE == 1) idct_combine_tile<LG, lrows, PIPE_THREADS>(buf, tid, wwS);
-        fft_tile_pipe<LG, lrows, PIPE_THREADS>(buf, tid, twS);
+        if (MODE == 1) idct_combine_tile<LG, lrows, PIPE_THREADS>(buf, tid, wwA);
+        fft_tile_pipe<LG, lrows, PIPE_THREADS>(buf, tid, twA);
         {
             // item u of this thread: pair r0, k = k0 + u * (threads / NP)
             const int r0 = tid & (NP - 1), k0 = tid >> lrows;
@@ -981,7 +1013,7 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
             for (int u = 0; u < 2 * PIPE_IT; ++u) {
                 const int k = k0 + u * (PIPE_THREADS >> lrows);
                 double2 v;
-                if (MODE == 0) v = dct_post<lrows>(rr, k, n, LG, wwS);
+                if (MODE == 0) v = dct_post<lrows>(rr, k, n, LG, wwA);
                 else v = rr[padi(bitrev(makhoul(k, n), LG)) << lrows];
                 *(double2 *)o = v;
                 o += ostep;
@@ -1580,7 +1612,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (map.es % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     // fused t-axis solve, pipelined: eigenvalue tables in LDS, a tile = consecutive columns of one x
-    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 7 && lg <= 10 && map.outerStride == 0 && map.es == map.nin) {
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 5 && lg <= 10 && map.outerStride == 0 && map.es == map.nin) {
         const i64 tileLines = ((i64)2 << TS_LG_CPLX) / n;
         const i64 nxv = sa.ny > 0 ? sa.nplane / sa.ny : 0;
         const size_t ldsPipe = (((size_t)2 << TS_LG_CPLX) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
@@ -1592,23 +1624,25 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
             const int nTiles = (int)(map.nLines / tileLines);
             static unsigned long long done_tp = 0;
             if (DeviceOnce once_(done_tp); once_) {
+                allow_big_lds(k_dct_tsolve_pipe<5>); allow_big_lds(k_dct_tsolve_pipe<6>);
                 allow_big_lds(k_dct_tsolve_pipe<7>); allow_big_lds(k_dct_tsolve_pipe<8>);
                 allow_big_lds(k_dct_tsolve_pipe<9>); allow_big_lds(k_dct_tsolve_pipe<10>);
             }
 #define TPIPE_LAUNCH(LGV)                                                                                              \
     hipLaunchKernelGGL((k_dct_tsolve_pipe<LGV>), dim3((unsigned)G), dim3(TS_THREADS), ldsPipe, st, src, dst, map, nTiles, sa, \
                        p->tw, p->ww)
-            if (lg == 10) TPIPE_LAUNCH(10); else if (lg == 9) TPIPE_LAUNCH(9); else if (lg == 8) TPIPE_LAUNCH(8); else TPIPE_LAUNCH(7);
+            if (lg == 10) TPIPE_LAUNCH(10); else if (lg == 9) TPIPE_LAUNCH(9); else if (lg == 8) TPIPE_LAUNCH(8);
+            else if (lg == 7) TPIPE_LAUNCH(7); else if (lg == 6) TPIPE_LAUNCH(6); else TPIPE_LAUNCH(5);
 #undef TPIPE_LAUNCH
             DS_HIP(hipGetLastError());
             return 0;
         }
     }
     // pipelined persistent kernel (see k_dct_axis0_pipe): whole tiles of 4096 complex values, the chip filled twice over
-    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 10 && map.es == map.nin) {
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 11 && map.es == map.nin) {
         const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
-        const int G = device_cus() & ~15;
-        if (map.nin % tileLines == 0 && map.nLines % tileLines == 0 && G >= 16 && map.nLines / tileLines >= 2 * (i64)G &&
+        const int G = device_cus() & ~31;
+        if (map.nin % tileLines == 0 && map.nLines % tileLines == 0 && G >= 32 && map.nLines / tileLines >= 2 * (i64)G &&
             map.nLines / tileLines < (1ll << 30)) {
             const int nTiles = (int)(map.nLines / tileLines);
             static unsigned long long done_sp = 0;
@@ -1617,16 +1651,19 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
                 allow_big_lds(k_dct_strided_pipe<0, 8>); allow_big_lds(k_dct_strided_pipe<1, 8>);
                 allow_big_lds(k_dct_strided_pipe<0, 9>); allow_big_lds(k_dct_strided_pipe<1, 9>);
                 allow_big_lds(k_dct_strided_pipe<0, 10>); allow_big_lds(k_dct_strided_pipe<1, 10>);
+                allow_big_lds(k_dct_strided_pipe<0, 11>); allow_big_lds(k_dct_strided_pipe<1, 11>);
             }
-            const size_t ldsPipe = (((size_t)2 << PIPE_LG_CPLX) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
+            // tables: n / 2 twiddles + n weights (2048-point lines: n / 4 + n / 2 + 1, TwQuarter / WwHalf)
+            const size_t ntab = lg > 10 ? (size_t)(n >> 2) + (size_t)(n >> 1) + 1 : (size_t)(n >> 1) + (size_t)n;
+            const size_t ldsPipe = (((size_t)2 << PIPE_LG_CPLX) + ntab) * sizeof(double2);
 #define SPIPE_LAUNCH(M, LGV)                                                                                         \
     hipLaunchKernelGGL((k_dct_strided_pipe<M, LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, \
                        nTiles, p->tw, p->ww)
             if (mode == 0) {
-                if (lg == 10) SPIPE_LAUNCH(0, 10); else if (lg == 9) SPIPE_LAUNCH(0, 9);
+                if (lg == 11) SPIPE_LAUNCH(0, 11); else if (lg == 10) SPIPE_LAUNCH(0, 10); else if (lg == 9) SPIPE_LAUNCH(0, 9);
                 else if (lg == 8) SPIPE_LAUNCH(0, 8); else SPIPE_LAUNCH(0, 7);
             } else {
-                if (lg == 10) SPIPE_LAUNCH(1, 10); else if (lg == 9) SPIPE_LAUNCH(1, 9);
+                if (lg == 11) SPIPE_LAUNCH(1, 11); else if (lg == 10) SPIPE_LAUNCH(1, 10); else if (lg == 9) SPIPE_LAUNCH(1, 9);
                 else if (lg == 8) SPIPE_LAUNCH(1, 8); else SPIPE_LAUNCH(1, 7);
             }
 #undef SPIPE_LAUNCH
@@ -1773,7 +1810,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         }
         // pipelined persistent kernel: whole tiles of 8192 doubles, enough of them to fill the chip twice
         const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
-        if (dct_pipe_enabled() && dct_wg_enabled() && lg >= 7 && lg <= 10 && map.nLines % tileLines == 0 &&
+        if (dct_pipe_enabled() && dct_wg_enabled() && lg >= 7 && lg <= 11 && map.nLines % tileLines == 0 &&
             (((uintptr_t)src | (uintptr_t)dst) % 16 == 0)) {
             const i64 nTiles = map.nLines / tileLines;
             const int ncu = device_cus();
@@ -1784,17 +1821,19 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
                     allow_big_lds(k_dct_axis0_pipe<false, 8>); allow_big_lds(k_dct_axis0_pipe<true, 8>);
                     allow_big_lds(k_dct_axis0_pipe<false, 9>); allow_big_lds(k_dct_axis0_pipe<true, 9>);
                     allow_big_lds(k_dct_axis0_pipe<false, 10>); allow_big_lds(k_dct_axis0_pipe<true, 10>);
+                    allow_big_lds(k_dct_axis0_pipe<false, 11>); allow_big_lds(k_dct_axis0_pipe<true, 11>);
                 }
                 const size_t rs = (size_t)n + 1;
-                const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2);
+                const size_t ntab = lg > 10 ? (size_t)(n >> 2) + (size_t)(n >> 1) + 1 : (size_t)(n >> 1) + (size_t)n;
+                const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + ntab) * sizeof(double2);
 #define PIPE_LAUNCH(INV, LGV)                                                                                        \
     hipLaunchKernelGGL((k_dct_axis0_pipe<INV, LGV>), dim3((unsigned)ncu), dim3(PIPE_THREADS), ldsPipe, st, src, dst, \
                        (int)nTiles, p->tw, p->ww)
                 if (inverse) {
-                    if (lg == 10) PIPE_LAUNCH(true, 10); else if (lg == 9) PIPE_LAUNCH(true, 9);
+                    if (lg == 11) PIPE_LAUNCH(true, 11); else if (lg == 10) PIPE_LAUNCH(true, 10); else if (lg == 9) PIPE_LAUNCH(true, 9);
                     else if (lg == 8) PIPE_LAUNCH(true, 8); else PIPE_LAUNCH(true, 7);
                 } else {
-                    if (lg == 10) PIPE_LAUNCH(false, 10); else if (lg == 9) PIPE_LAUNCH(false, 9);
+                    if (lg == 11) PIPE_LAUNCH(false, 11); else if (lg == 10) PIPE_LAUNCH(false, 10); else if (lg == 9) PIPE_LAUNCH(false, 9);
                     else if (lg == 8) PIPE_LAUNCH(false, 8); else PIPE_LAUNCH(false, 7);
                 }
 #undef PIPE_LAUNCH

@@ -6,7 +6,9 @@
     time chunks) so that the production geometry of the headline config meets the oracle inside the GPU suite;
   * one rank's share of configs[3], 2048 x 2048 x 32: run-to-run determinism, and the slab decomposition (two
     in-process slabs on their own streams -- the single-process multi-device path with both slabs on this box's
-    one device) reproduces the single slab <= 1e-10.
+    one device) reproduces the single slab <= 1e-10;
+  * 2048 x 2048 x 128 (half the time axis: what one MI355X's 288 GB hold) as one slab and as four slabs of one
+    rank's share each: phi, q <= 1e-10.
 
 The reference itself cannot run 2048 x 2048 x 256 (32-bit index arithmetic in its MEX binaries), so
 the oracle at reduced nt is the only checker for this grid."""
@@ -46,8 +48,8 @@ def test_large_spatial_grid_against_oracle(n, nt, K):
     assert max(errs.values()) <= 1e-9, errs
 
 
-def _run_share(K, **kw):
-    ny, nx, nt = 2048, 2048, 32
+def _run_share(K, nt=32, **kw):
+    ny, nx = 2048, 2048
     rho0, rho1 = get_example_2d("example1", ny, nx)
     var, model = D.initialize(rho0, rho1, nt, lazy_zeros=True)
     D.InitialScaling(var, model, True, None, dim=2)
@@ -71,6 +73,24 @@ def test_config4_rank_share_deterministic_and_slab_invariant():
     del b
     assert np.all(np.isfinite(ha["kkt"])) and ha["iter"][-1] == K
     c, hc, sc = _run_share(K, ngpu=2)       # two slabs, own streams, peer copies (one device here)
+    assert abs(sc - sa) <= 1e-12 * abs(sa)
+    np.testing.assert_array_equal(hc["iter"], ha["iter"])
+    np.testing.assert_allclose(hc["kkt"], ha["kkt"], rtol=1e-7, atol=1e-10)
+    for f in ("phi", "q"):
+        err = _relerr(c[f], a[f])
+        assert err <= 1e-10, (f, err)
+
+
+def test_config4_half_of_the_grid_in_four_slabs():
+    """2048 x 2048 x 128 -- half of configs[3]'s time axis, the most of it one MI355X holds (about 196 GB of device
+    state) -- as ONE slab and as FOUR in-process time slabs (each slab 2048 x 2048 x 32 = one rank's share of the
+    8-GPU run, with its own streams, halo exchanges and the partitioned tridiagonal t-solve): identical KKT schedule,
+    phi and q <= 1e-10.  The single slab runs the fused t-axis DCT pass, the slabs the tridiagonal solve, so the two
+    runs also hold the two Poisson solvers against each other at this size."""
+    K = 4                                   # one KKT check (iteration 3) with its sigma update on the way
+    a, ha, sa = _run_share(K, nt=128)
+    assert np.all(np.isfinite(ha["kkt"])) and ha["iter"][-1] == K
+    c, hc, sc = _run_share(K, nt=128, ngpu=4)
     assert abs(sc - sa) <= 1e-12 * abs(sa)
     np.testing.assert_array_equal(hc["iter"], ha["iter"])
     np.testing.assert_allclose(hc["kkt"], ha["kkt"], rtol=1e-7, atol=1e-10)

@@ -147,7 +147,9 @@ def test_prime_factor_dct_against_the_dense_product():
                                    (512, 512, 64), (256, 256, 256), (128, 128, 1024), (1024, 128, 128),
                                    # tile counts that do not divide by the persistent grid: workgroups with two and with
                                    # three tiles (first / steady / last wait counts of the LDS-DMA pipeline)
-                                   (1024, 1024, 5), (512, 1024, 9)])
+                                   (1024, 1024, 5), (512, 1024, 9),
+                                   # 2048-point lines in the pipelined kernels (quarter / half tables in LDS, tiles of two pairs)
+                                   (2048, 512, 4), (512, 2048, 5), (2048, 2048, 3)])
 def test_dctn_many_lines(shape):
     """Many lines per axis (every workgroup of the chip busy several times over), odd line counts, dense x / t axes."""
     a = np.asfortranarray(rng.standard_normal(shape))
@@ -160,7 +162,9 @@ def test_dctn_many_lines(shape):
                                       (64, 64, 65), (7, 3, 513),
                                       # large enough for the pipelined kernels (fused t-axis solve of length 128 .. 1024)
                                       (256, 128, 128), (128, 512, 256), (64, 512, 512), (32, 1024, 1024),
-                                      (256, 160, 128), (64, 1000, 128)])        # tile counts that leave a remainder
+                                      (256, 160, 128), (64, 1000, 128),        # tile counts that leave a remainder
+                                      # short time axes in the pipelined t pass (tiles of 64 / 32 pairs of columns)
+                                      (512, 512, 32), (256, 1024, 64), (1024, 300, 32)])
 def test_oper_poisson(ny, nx, nt):
     Dsc = 0.37
     rhs = np.asfortranarray(rng.standard_normal((ny, nx, nt)))
