@@ -1313,7 +1313,7 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
             if (AXIS0) {
                 const i64 L = L0 + x_ll + ZSTEP * u;
                 const int j = j0 + x_jj;
-                xreg[u] = (L < map.nLines && j < n) ? src[map.base(L) + j] : 0.0;
+                xreg[u] = (L < map.nLines && j < n) ? src[L * map.outerStride + j] : 0.0;     // axis 0: nin = 1
             } else {
                 const int j = j0 + x_jj + 2 * u;
                 xreg[u] = (x_ok && j < n) ? src[xbase + (i64)j * map.es] : 0.0;
@@ -1365,7 +1365,7 @@ __global__ void __launch_bounds__(256) k_dct_mfma(const double *__restrict__ src
                 if (AXIS0) {
                     const int k = k0 + a * 16 + li;
                     const i64 L = L0 + wave * 32 + b * 16 + lh + 4 * r;
-                    if (k < n && L < map.nLines) dst[map.base(L) + k] = acc[a][b][r];
+                    if (k < n && L < map.nLines) dst[L * map.outerStride + k] = acc[a][b][r];
                 } else {
                     const int k = k0 + a * 16 + lh + 4 * r;
                     const i64 L = L0 + wave * 32 + b * 16 + li;
@@ -1423,7 +1423,7 @@ __global__ void __launch_bounds__(256) k_dct_mfma_split(const double *__restrict
         x_ok = (L0 + x_ll) < map.nLines;
         xbase = x_ok ? map.base(L0 + x_ll) : 0;
     }
-    auto at = [&](i64 L, i64 lbase, int j) { return AXIS0 ? src[map.base(L) + j] : src[lbase + (i64)j * map.es]; };
+    auto at = [&](i64 L, i64 lbase, int j) { return AXIS0 ? src[L * map.outerStride + j] : src[lbase + (i64)j * map.es]; };
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         const int par = INV ? ph : (int)blockIdx.z;               // 0: even part, 1: odd part
@@ -1503,7 +1503,7 @@ __global__ void __launch_bounds__(256) k_dct_mfma_split(const double *__restrict
                 const int o = o0 + a * 16 + (AXIS0 ? li : lh + 4 * r);
                 const i64 L = L0 + wave * 32 + b * 16 + (AXIS0 ? lh + 4 * r : li);
                 if (o >= nout || L >= map.nLines) continue;
-                const i64 lbase = map.base(L);
+                const i64 lbase = AXIS0 ? L * map.outerStride : map.base(L);
                 const i64 es = map.es;
                 if (!INV) {
                     dst[lbase + (i64)(2 * o + (int)blockIdx.z) * es] = acc[0][a][b][r];

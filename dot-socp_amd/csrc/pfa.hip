@@ -197,8 +197,15 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
     const double *sp = src + row * g.srow + y0 + 2 * r;
     double *dp = dst + row * g.drow + y0 + 2 * r;
     double2 *mine = tile + r * N;
+    // VEC: every pair starts on an even element and -- when the row has an odd number of lines -- its pitch leaves room
+    // for one more element, so the last pair of a row is fetched and stored as 16 bytes too; what comes in from the pad
+    // is replaced by zero (the pad receives the rounding-level transform of that zero line and is never used as data)
     auto ld2 = [&](i64 off) -> double2 {
-        if (VEC) return okA ? *(const double2 *)(sp + off) : make_double2(0.0, 0.0);     // ny even: okA implies okB
+        if (VEC) {
+            double2 v = okA ? *(const double2 *)(sp + off) : make_double2(0.0, 0.0);
+            if (!okB) v.y = 0.0;
+            return v;
+        }
         return make_double2(okA ? sp[off] : 0.0, okB ? sp[off + 1] : 0.0);
     };
     auto st2 = [&](i64 off, double a, double b) {
@@ -598,8 +605,11 @@ int pfa_launch_strided(const PfaPlan *p, const double *src, double *dst, i64 nyL
         sa.kscale = sargs->kscale; sa.cy = sargs->cy; sa.cx = sargs->cx; sa.ct = sargs->ct;
         sa.nyE = sargs->nyE; sa.line0 = sargs->line0; sa.gRow = sargs->gRow;
     }
-    // one 16-byte access carries both lines of a pair when every pair starts on an even element
-    const bool vec = (nyLines % 2 == 0) && (srow % 2 == 0) && (sel % 2 == 0) && (drow % 2 == 0) && (del % 2 == 0) &&
+    // one 16-byte access carries both lines of a pair when every pair starts on an even element; a row with an odd
+    // number of lines needs one pad element behind its last line (pitched rows: common.h)
+    const bool roomy = (nyLines % 2 == 0) ||
+                       ((nrows == 1 || (srow > nyLines && drow > nyLines)) && sel > nyLines && del > nyLines);
+    const bool vec = roomy && (srow % 2 == 0) && (sel % 2 == 0) && (drow % 2 == 0) && (del % 2 == 0) &&
                      (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     switch (p->n) {
 #define X(NV) case NV: pfa_launch_strided_n<NV>(p, src, dst, g, sa, mode, vec, (unsigned)tiles, st); break;

@@ -110,17 +110,39 @@ int Solver::palm_step(bool *brk) {
     z_prev_ok = false;
     DS_CHECK(phase_z_tails());            // time slabs: phi^{k+1} head -> left, adjoint tails -> right
     // ---- second q-step + alpha :213-218,221,225 ----
+    // Whether the iteration ends with a KKT check (:231-232) is known here (the time limit is the one trigger that is
+    // not: such a check takes the unfolded block).  If it does, the q-step runs in the flavour that accumulates its share
+    // of the KKT sums -- everything made of phi^{k+1}, q^{k+1}, alpha^{k+1}, A phi and c -- as in the inPALM loop
+    // (Solver::phase_q; the right-hand side it also writes is not used: PALM's first q-step forms its own), and the
+    // cell pass of the block then carries the pending multiplier step, the cell sums and F*B*beta (Solver::kkt_sums).
+    const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                 // :231
+    const bool kkt_due = opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit;
+    const bool fold = kkt_due && kkt_fold && qrhs;
     prof_begin(PH_QSTEP);
-    FOR_SLABS(s)
-        DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, s.tail_bx, s.tail_by, s.q, s.alpha,
-                                    s.st));
+    if (fold) {
+        const KktCoef k = kkt_coef();
+        FOR_SLABS(s) {
+            DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+            QStepExtra ex{};
+            ex.apend = 0; ex.amul = 1.0; ex.adiv = 1.0;
+            ex.partials = kkt_qstep_partials(s.g, s.kw);
+            ex.resid = s.w1;                       // free between the Poisson solves
+            ex.kappa = k.kappa; ex.dsD = k.dsD;
+            DS_CHECK(launch_qstep_rhs(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, s.tail_bx, s.tail_by, s.c, s.q, s.alpha,
+                                      s.alpha2, s.w0, s.st, 0, -1, 1, &ex));
+            std::swap(s.alpha, s.alpha2);
+        }
+    } else {
+        FOR_SLABS(s)
+            DS_CHECK(launch_qstep_fused(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, nullptr, s.tail_bx, s.tail_by, s.q, s.alpha,
+                                        s.st));
+    }
     prof_end(PH_QSTEP);
     DS_CHECK(exchange_q_halo(false));     // time slabs: q^{k+1} halo (multiplier step, KKT block)
     deferred = true;                       // beta^{k+1}: :222-226, executed by the next pass over beta
-    const bool adjustSigmaYes = if_adjust_sigma((double)it, lastSigmaIt);                 // :231
     const bool timed_out = elapsed() > time_limit;
-    if (opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out)       // :232
-        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
+    if (kkt_due || timed_out)                                                             // :232
+        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk, fold));
     return 0;
 }
 

@@ -130,3 +130,31 @@ def test_wide_qstep_tile_changes_nothing(ny, nx, nt, K, monkeypatch):
     np.testing.assert_array_equal(h1["kkt"], h0["kkt"])
     for f in FIELDS:
         np.testing.assert_array_equal(getattr(got, f), getattr(ref, f))
+
+
+@pytest.mark.parametrize("ny,nx,nt,K,ngpu", [(32, 32, 16, 40, None), (65, 129, 17, 25, None), (100, 70, 20, 30, None),
+                                              (64, 48, 24, 30, 3), (33, 33, 17, 25, 2)])
+def test_palm_folded_equals_unfolded(ny, nx, nt, K, ngpu, monkeypatch):
+    """PALM (solver_socp_PALM.m:231-232 calls the same KKT block): on an iteration that ends with a check its second
+    q-step runs in the KKT flavour of k_qstep_rhs and the block takes the folded cell pass -- against the unfolded block
+    of the same library (DOTSOCP_KKT_FOLD=0), on one slab (pitched and unpitched rows) and on in-process time slabs."""
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DOTSOCP_KKT_FOLD", flag)
+        var, model = D.initialize(rho0, rho1, nt)
+        o = OD.default_opts(dict(tol=0.0, maxit=K), "PALM", False)
+        D.InitialScaling(var, model, o["scaling"], None, dim=2)
+        ctx = D.InPALMContext(var, o, model, method="PALM", ngpu=ngpu)
+        ctx.run(-1)
+        hist, sigma = ctx.finish(download=True)
+        ctx.close()
+        res[flag] = (var, hist, sigma)
+    (ref, h0, s0), (got, h1, s1) = res["0"], res["1"]
+    np.testing.assert_array_equal(h1["iter"], h0["iter"])
+    assert len(h0["iter"]) >= 4 and abs(s1 - s0) <= 1e-13 * abs(s0)
+    np.testing.assert_allclose(h1["kkt"], h0["kkt"], rtol=1e-9, atol=1e-10)
+    for f in FIELDS:
+        a, b = getattr(got, f), getattr(ref, f)
+        err = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        assert err <= 1e-12, (f, err)
