@@ -71,12 +71,16 @@ DctPlan *dct_plan_create(i64 n) {
         (void)hipMemcpy(p->tw, tw.data(), sizeof(double2) * (n / 2), hipMemcpyHostToDevice);
         (void)hipMemcpy(p->ww, ww.data(), sizeof(double2) * n, hipMemcpyHostToDevice);
     } else {
-        if (pfa_supported(n)) {
+        static const bool pfa_on = !(getenv("DOTSOCP_PFA") && atoi(getenv("DOTSOCP_PFA")) == 0);
+        if (pfa_supported(n) && pfa_on) {
+            // the prime-factor transform needs three small tables; the n x n matrices of the dense product (16 MB and
+            // two million long-double cosines at n = 1025) are not built
             p->pfa = pfa_plan_create(n);
             if (!p->pfa) {
                 dct_plan_destroy(p);
                 return nullptr;
             }
+            return p;
         }
         std::vector<double> cf((size_t)n * n), ci((size_t)n * n);
         for (i64 k = 0; k < n; ++k) {

@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -509,16 +510,23 @@ void pfa_plan_destroy(PfaPlan *p) {
 }
 
 // tile shape per length: P pairs of lines per workgroup of T threads (LDS = P * n * 16 bytes)
+#ifndef PFA_P0_1025
+#define PFA_P0_1025 4
+#define PFA_T0_1025 512
+#define PFA_P0_513 8
+#define PFA_T0_513 512
+#endif
 template <int N> struct PfaShape;
-template <> struct PfaShape<1025> { typedef PfaDims<25, 41> D; static constexpr int P = 4, T = 512; };
-template <> struct PfaShape<513> { typedef PfaDims<27, 19> D; static constexpr int P = 8, T = 512; };
-template <> struct PfaShape<129> { typedef PfaDims<3, 43> D; static constexpr int P = 16, T = 256; };
-template <> struct PfaShape<65> { typedef PfaDims<5, 13> D; static constexpr int P = 32, T = 256; };
-template <> struct PfaShape<33> { typedef PfaDims<3, 11> D; static constexpr int P = 32, T = 256; };
-template <> struct PfaShape<17> { typedef PfaDims<1, 17> D; static constexpr int P = 32, T = 256; };
-template <> struct PfaShape<9> { typedef PfaDims<9, 1> D; static constexpr int P = 32, T = 256; };
-template <> struct PfaShape<5> { typedef PfaDims<5, 1> D; static constexpr int P = 32, T = 256; };
-template <> struct PfaShape<3> { typedef PfaDims<3, 1> D; static constexpr int P = 32, T = 256; };
+// (P0, T0: the same for the axis-0 kernels, whose lines are contiguous in memory whatever the tile holds)
+template <> struct PfaShape<1025> { typedef PfaDims<25, 41> D; static constexpr int P = 4, T = 512, P0 = PFA_P0_1025, T0 = PFA_T0_1025; };
+template <> struct PfaShape<513> { typedef PfaDims<27, 19> D; static constexpr int P = 8, T = 512, P0 = PFA_P0_513, T0 = PFA_T0_513; };
+template <> struct PfaShape<129> { typedef PfaDims<3, 43> D; static constexpr int P = 16, T = 256, P0 = 16, T0 = 256; };
+template <> struct PfaShape<65> { typedef PfaDims<5, 13> D; static constexpr int P = 32, T = 256, P0 = 32, T0 = 256; };
+template <> struct PfaShape<33> { typedef PfaDims<3, 11> D; static constexpr int P = 32, T = 256, P0 = 32, T0 = 256; };
+template <> struct PfaShape<17> { typedef PfaDims<1, 17> D; static constexpr int P = 32, T = 256, P0 = 32, T0 = 256; };
+template <> struct PfaShape<9> { typedef PfaDims<9, 1> D; static constexpr int P = 32, T = 256, P0 = 32, T0 = 256; };
+template <> struct PfaShape<5> { typedef PfaDims<5, 1> D; static constexpr int P = 32, T = 256, P0 = 32, T0 = 256; };
+template <> struct PfaShape<3> { typedef PfaDims<3, 1> D; static constexpr int P = 32, T = 256, P0 = 32, T0 = 256; };
 
 #define PFA_FOR_LENGTHS(X) X(1025) X(513) X(129) X(65) X(33) X(17) X(9) X(5) X(3)
 
@@ -537,7 +545,8 @@ static void pfa_raise_lds() {
     PFA_RAISE((k_pfa_strided<D, P, T, 0, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 0, false>));
     PFA_RAISE((k_pfa_strided<D, P, T, 1, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 1, false>));
     PFA_RAISE((k_pfa_strided<D, P, T, 2, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 2, false>));
-    PFA_RAISE((k_pfa_axis0<D, P, T, false>)); PFA_RAISE((k_pfa_axis0<D, P, T, true>));
+    PFA_RAISE((k_pfa_axis0<D, S::P0, S::T0, false>)); PFA_RAISE((k_pfa_axis0<D, S::P0, S::T0, true>));
+    PFA_RAISE((k_pfa_axis0<D, S::P0 / 2, 256, false>)); PFA_RAISE((k_pfa_axis0<D, S::P0 / 2, 256, true>));
 #undef PFA_RAISE
 }
 
@@ -565,18 +574,28 @@ static void pfa_launch_strided_n(const PfaPlan *p, const double *src, double *ds
 #undef PFA_GO
 }
 
-template <int N>
-static void pfa_launch_axis0_n(const PfaPlan *p, const double *src, double *dst, i64 nLines, i64 sline, i64 dline,
-                               int inverse, hipStream_t st) {
-    typedef PfaShape<N> S;
-    typedef typename S::D D;
-    constexpr int P = S::P, T = S::T;
-    const size_t lds = (size_t)P * N * sizeof(double2);
+template <class D, int P, int T>
+static void pfa_launch_axis0_pt(const PfaPlan *p, const double *src, double *dst, i64 nLines, i64 sline, i64 dline,
+                                int inverse, hipStream_t st) {
+    const size_t lds = (size_t)P * D::N * sizeof(double2);
     const unsigned blocks = (unsigned)((nLines + 2 * P - 1) / (2 * P));
     if (inverse)
         hipLaunchKernelGGL((k_pfa_axis0<D, P, T, true>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
     else
         hipLaunchKernelGGL((k_pfa_axis0<D, P, T, false>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
+}
+
+template <int N>
+static void pfa_launch_axis0_n(const PfaPlan *p, const double *src, double *dst, i64 nLines, i64 sline, i64 dline,
+                               int inverse, hipStream_t st) {
+    typedef PfaShape<N> S;
+    typedef typename S::D D;
+    // DOTSOCP_PFA_AX0=1: half the tile (twice the workgroups per CU) along axis 0 for the two long lengths -- A/B switch
+    static const int alt = getenv("DOTSOCP_PFA_AX0") ? atoi(getenv("DOTSOCP_PFA_AX0")) : 0;
+    if constexpr (N == 1025 || N == 513) {
+        if (alt == 1) { pfa_launch_axis0_pt<D, S::P0 / 2, 256>(p, src, dst, nLines, sline, dline, inverse, st); return; }
+    }
+    pfa_launch_axis0_pt<D, S::P0, S::T0>(p, src, dst, nLines, sline, dline, inverse, st);
 }
 
 template <int N>
