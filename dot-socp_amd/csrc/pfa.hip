@@ -546,7 +546,6 @@ static void pfa_raise_lds() {
     PFA_RAISE((k_pfa_strided<D, P, T, 1, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 1, false>));
     PFA_RAISE((k_pfa_strided<D, P, T, 2, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 2, false>));
     PFA_RAISE((k_pfa_axis0<D, S::P0, S::T0, false>)); PFA_RAISE((k_pfa_axis0<D, S::P0, S::T0, true>));
-    PFA_RAISE((k_pfa_axis0<D, S::P0 / 2, 256, false>)); PFA_RAISE((k_pfa_axis0<D, S::P0 / 2, 256, true>));
 #undef PFA_RAISE
 }
 
@@ -590,11 +589,8 @@ static void pfa_launch_axis0_n(const PfaPlan *p, const double *src, double *dst,
                                int inverse, hipStream_t st) {
     typedef PfaShape<N> S;
     typedef typename S::D D;
-    // DOTSOCP_PFA_AX0=1: half the tile (twice the workgroups per CU) along axis 0 for the two long lengths -- A/B switch
-    static const int alt = getenv("DOTSOCP_PFA_AX0") ? atoi(getenv("DOTSOCP_PFA_AX0")) : 0;
-    if constexpr (N == 1025 || N == 513) {
-        if (alt == 1) { pfa_launch_axis0_pt<D, S::P0 / 2, 256>(p, src, dst, nLines, sline, dline, inverse, st); return; }
-    }
+    // (measured and dropped: half the tile = twice the workgroups per CU along axis 0 -- Poisson solve 3.23 vs 3.26 ms at
+    // 1025 x 1025 x 129, 0.805 vs 0.796 ms at 513 x 513 x 129: these passes are not occupancy-bound)
     pfa_launch_axis0_pt<D, S::P0, S::T0>(p, src, dst, nLines, sline, dline, inverse, st);
 }
 
