@@ -615,10 +615,6 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_strided(const double *__res
 // staged row of the per-wave flavour above at the same LDS footprint -- the footprint, not registers,
 // caps the resident workgroups per CU, so this doubles the waves that overlap VALU, LDS and HBM phases.
 // ---------------------------------------------------------------------------------------------
-// Workgroup barrier that leaves the vector-memory counter alone: LDS hand-off only.  The pipelined kernels keep LDS-DMA
-// loads and global stores in flight across barriers (counted s_waitcnt vmcnt(N) of their own), which a fence would drain.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <bool RAWB = false>
 __device__ __forceinline__ void fft_rows_wg(double2 *rows, int lrows, int lg, int rowStride, int t, int T,
                                             const double2 *__restrict__ tw) {
@@ -763,15 +759,6 @@ __device__ __forceinline__ double sload_f64(const double *p) {
     double v;
     asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sp) : "memory");
     return v;
-}
-
-// one wave-instruction: 64 lanes x 16 B from each lane's global address to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform)
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
 }
 
 // the register groups of fft_rows_wg for a length known at compile time (same plan, same arithmetic)

@@ -33,6 +33,19 @@ __device__ __forceinline__ BlockId block_id(bool remap) {
     return b;
 }
 
+// Workgroup barrier that leaves the vector-memory counter alone: LDS hand-off only.  The pipelined kernels keep LDS-DMA
+// loads and global stores in flight across barriers (counted s_waitcnt vmcnt(N) of their own), which a fence would drain.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one wave-instruction: 64 lanes x 16 B from each lane's global address to LDS [lds_dst + 16 * lane] (lds_dst wave-uniform)
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 // Row projection onto {x1 >= ||x_2..K||}; literal restatement of mexProjSoc's arithmetic
 // (SURVEY.md 8a a1): n = ||x_2..K||, c = clamp((x1/n + 1)/2, 0, 1) with NaN passing through,
 // x_j <- c x_j, x_1 <- (c >= 1) ? x_1 : c n.

@@ -174,7 +174,11 @@ typedef struct {
  *     partial sums are added up on the host.  This is what a single MATLAB process (solver_dotsocp2d.m:208 calls
  *     the loop synchronously from the interpreter thread) uses: opts.ngpu of the MEX gateway.  With fewer devices
  *     than slabs, slabs share devices (one device: same as dotsocp_create(prob, device, ngpu)).  upload / download /
- *     recover_outputs take and return the GLOBAL fields, exactly as with one slab; or
+ *     recover_outputs take and return the GLOBAL fields, exactly as with one slab.  STATUS: every loop is verified with
+ *     2 .. 8 slabs on concurrent streams of ONE device (the build's boxes have one GPU); slabs on DIFFERENT devices
+ *     (hipDeviceEnablePeerAccess, hipMemcpyPeerAsync, cross-device stream waits) have never run on hardware.  Between
+ *     different devices messages travel as event-ordered peer copies by default; the launches that pull them through
+ *     peer pointers are opt-in there (DOTSOCP_MSG_BATCH=1, DOTSOCP_TRI_GATHER=1); or
  *   - one process per GPU: dotsocp_create(prob, device, 1) + dotsocp_attach_rccl() (bench.py, torch.distributed). */
 dotsocp_ctx *dotsocp_create(const dotsocp_problem *prob, int device, int nslabs);
 dotsocp_ctx *dotsocp_create_multi(const dotsocp_problem *prob, int first_device, int ngpu);
