@@ -14,7 +14,8 @@
 // s_load: no LDS traffic, one v_fma_f64 per multiply-add with an SGPR operand) and writes the outputs in place.
 // 1025-point line: 25 x 800 + 41 x 288 = 31.8k multiply-adds per real line instead of the 525k of the dense DCT
 // product (k_dct_mfma_split), all of them on the vector ALU -- the fp64 matrix cores have the same peak rate as the
-// vector fp64 pipe on this chip, so 16x fewer operations beat the contraction.  The passes are HBM-bound again.
+// vector fp64 pipe on this chip, so 16x fewer operations beat the contraction.  The passes run at 2.5 - 3.8 TB/s, bound by
+// their own vector-ALU work (see pfa_launch_axis0_n), 6x faster than the dense product.
 #include "device_utils.h"
 #include "kernels.h"
 #include "pfa.h"
@@ -118,8 +119,7 @@ __device__ __forceinline__ void pfa_small_dft(double *__restrict__ p, const int 
 }
 
 // both stages on a tile of P line pairs ([P][N1][N2] complex values), ending with a workgroup barrier
-// (RAWB: the barrier that leaves LDS-DMA loads and global stores in flight, for the pipelined kernel)
-template <class PF, int P, int T, bool RAWB = false>
+template <class PF, int P, int T>
 __device__ __forceinline__ void pfa_tile_dft(double2 *tile, int tid, ctab_t tab1, ctab_t tab2) {
     constexpr int N1 = PF::N1, N2 = PF::N2, N = PF::N;
     if constexpr (N2 > 1) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void pfa_tile_dft(double2 *tile, int tid, ctab_t tab1
             const int part = item & 1, row = item >> 1;
             pfa_small_dft<N2, 2>((double *)(tile + row * N2) + part, part, tab2);
         }
-        if (RAWB) lds_barrier(); else __syncthreads();
+        __syncthreads();
     }
     if constexpr (N1 > 1) {
         for (int item = tid; item < P * N2 * 2; item += T) {
@@ -135,7 +135,7 @@ __device__ __forceinline__ void pfa_tile_dft(double2 *tile, int tid, ctab_t tab1
             const int r = c / N2, k2 = c - r * N2;
             pfa_small_dft<N1, 2 * N2>((double *)(tile + r * N + k2) + part, part, tab1);
         }
-        if (RAWB) lds_barrier(); else __syncthreads();
+        __syncthreads();
     }
 }
 
@@ -432,157 +432,6 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_axis0(const d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Axis 0, pipelined (the scheme of k_dct_axis0_pipe, dct.hip): the non-pipelined kernels above are bound by bytes in
-// flight -- while a workgroup transforms, its tile sits in LDS and nothing of it travels (halving the tile for twice
-// the workgroups changes nothing).  ONE persistent workgroup of 512 threads per CU walks tiles of 2 P whole lines
-// (contiguous in memory: 2 P x lineStride doubles, <= 72 KB) through two LDS buffers; the lines of tile k+1 and k+2
-// arrive by LDS-DMA (global_load_lds_dwordx4: no registers) while tile k is transformed and stored.  Every wave counts
-// its own vector-memory operations: the next tile has landed when only the stores issued after its DMA are outstanding
-// (s_waitcnt vmcnt(#stores)), and one raw s_barrier then says both "all pieces of the next tile are in LDS" and "this
-// buffer is drained".  The counts must be the same for every wave and tile, so every wave issues the same number of
-// DMA pieces (9: the last ones reach past the tile and are clamped at the array's end) and of stores (work items
-// beyond the tile's last one repeat it: same value to the same address); only whole tiles are handled -- the lines
-// left over go to the kernel above.  Nothing in the loop is an ordinary global load (the compiler would wait for
-// everything in flight): the DCT weights live in LDS (half of them: ww[n - k] = (-imag ww[k], -real ww[k])), the small
-// DFT matrices come through the scalar cache.
-// ---------------------------------------------------------------------------------------------------------------
-#define PFA_PIPE_T 512
-#define PFA_PIPE_ND 9                       // DMA pieces (1 KB) per wave and tile: 8 waves x 9 KB = 72 KB per buffer
-#define PFA_PIPE_BUF (8 * PFA_PIPE_ND * 1024)
-
-template <class PF, int P, bool INV>
-__global__ void __launch_bounds__(PFA_PIPE_T) k_pfa_axis0_pipe(const double *__restrict__ src, double *__restrict__ dst,
-                                                               int nTiles, i64 sline, i64 dline, i64 srcDoubles,
-                                                               const double2 *__restrict__ ww, const double *__restrict__ t1,
-                                                               const double *__restrict__ t2) {
-    extern __shared__ double2 lds[];
-    constexpr int N = PF::N, NH = PF::NH, T = PFA_PIPE_T;
-    constexpr int LINES = 2 * P;
-    const ctab_t tab1 = as_ctab(t1), tab2 = as_ctab(t2);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double2 *wwS = (double2 *)((char *)lds + 2 * PFA_PIPE_BUF);           // ww[0 .. NH]
-    for (int i = tid; i <= NH; i += T) wwS[i] = ww[i];
-    auto wwk = [&](int k) { return wwS[k]; };                             // k <= NH
-    auto wwm = [&](int k) { const double2 v = wwS[k]; return make_double2(-v.y, -v.x); };   // ww[N - k], 1 <= k <= NH
-    const unsigned ldsBase = (unsigned)(uintptr_t)lds;
-    const i64 tileDoubles = (i64)LINES * sline;
-    auto dma = [&](int tile, int b) {
-        const i64 d0 = (i64)tile * tileDoubles + (i64)(wave * PFA_PIPE_ND) * 128 + lane * 2;    // first double of this lane's piece
-        const unsigned l0 = ldsBase + (unsigned)b * (unsigned)PFA_PIPE_BUF + (unsigned)(wave * PFA_PIPE_ND) * 1024u;
-#pragma unroll
-        for (int i = 0; i < PFA_PIPE_ND; ++i) {
-            i64 d = d0 + (i64)i * 128;
-            if (d + 2 > srcDoubles) d = 0;                                // past the array's end: any valid 16 bytes
-            glds16(src + d, l0 + (unsigned)i * 1024u);
-        }
-    };
-    int tile = blockIdx.x;
-    const int stride = gridDim.x;
-    if (tile < nTiles) dma(tile, 0);
-    if (tile + stride < nTiles) dma(tile + stride, 1);
-    if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PFA_PIPE_ND) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    constexpr int NS = INV ? (LINES * N + T - 1) / T : 4 * ((P * (NH + 1) + T - 1) / T);      // stores per wave and tile
-    for (int it = 0; tile < nTiles; tile += stride, ++it) {
-        const int b = it & 1;
-        double2 *buf = (double2 *)((char *)lds + b * PFA_PIPE_BUF);
-        const double *raw = (const double *)buf;                          // line l at raw + l * sline
-        // ---- raw lines -> [P][N1][N2] complex image (same buffer): all reads, barrier, all writes ----
-        if (!INV) {
-            constexpr int TOTAL = P * N, NIT = (TOTAL + T - 1) / T;
-            double2 v[NIT];
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int idx = tid + u * T;
-                const int r = idx / N, e = idx - r * N;
-                if (idx < TOTAL) v[u] = make_double2(raw[(i64)(2 * r) * sline + e], raw[(i64)(2 * r + 1) * sline + e]);
-            }
-            lds_barrier();
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int idx = tid + u * T;
-                const int r = idx / N, e = idx - r * N;
-                if (idx < TOTAL) buf[r * N + PF::posA(pfa_makhoul(e, N))] = v[u];
-            }
-        } else {
-            constexpr int TOTAL = P * (NH + 1), NIT = (TOTAL + T - 1) / T;
-            Pfa4 x[NIT];
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int idx = tid + u * T;
-                const int r = idx / (NH + 1), k = idx - r * (NH + 1);
-                if (idx < TOTAL) {
-                    const double *a = raw + (i64)(2 * r) * sline, *bb = a + sline;
-                    const int m = k ? N - k : 0;
-                    x[u].ak = a[k]; x[u].am = a[m]; x[u].bk = bb[k]; x[u].bm = bb[m];
-                }
-            }
-            lds_barrier();
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int idx = tid + u * T;
-                const int r = idx / (NH + 1), k = idx - r * (NH + 1);
-                if (idx >= TOTAL) continue;
-                double2 *mine = buf + r * N;
-                if (k == 0) {
-                    const double w0 = wwS[0].x;
-                    mine[0] = make_double2(w0 * x[u].ak, w0 * x[u].bk);
-                } else {
-                    double2 gk, gm;
-                    pfa_pre(x[u], wwk(k), wwm(k), gk, gm);
-                    mine[PF::posA(k)] = gk;
-                    mine[PF::posA(N - k)] = gm;
-                }
-            }
-        }
-        lds_barrier();
-        pfa_tile_dft<PF, P, T, true>(buf, tid, tab1, tab2);
-        // ---- post-processing + stores: every lane stores in every round (items past the last repeat it) ----
-        double *out = dst + (i64)tile * LINES * dline;
-        if (!INV) {
-            constexpr int TOTAL = P * (NH + 1), NIT = (TOTAL + T - 1) / T;
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                int idx = tid + u * T;
-                if (idx >= TOTAL) idx = TOTAL - 1;
-                const int r = idx / (NH + 1), k = idx - r * (NH + 1);
-                double *a = out + (i64)(2 * r) * dline, *bb = a + dline;
-                const double2 *mine = buf + r * N;
-                const int kk = k ? k : 1;                                // k = 0: placeholders, overwritten below
-                const int m = N - kk;
-                Pfa4 xx = pfa_post(mine[PF::posB(kk)], mine[PF::posB(m)], wwk(kk), wwm(kk));
-                int ka = kk, ma = m;
-                if (k == 0) {
-                    const double w0 = wwS[0].x;
-                    const double2 v0 = mine[0];
-                    xx.ak = xx.am = w0 * v0.x;
-                    xx.bk = xx.bm = w0 * v0.y;
-                    ka = ma = 0;
-                }
-                a[ka] = xx.ak; a[ma] = xx.am; bb[ka] = xx.bk; bb[ma] = xx.bm;
-            }
-        } else {
-            constexpr int TOTAL = LINES * N, NIT = (TOTAL + T - 1) / T;
-#pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                int idx = tid + u * T;
-                if (idx >= TOTAL) idx = TOTAL - 1;
-                const int l = idx / N, e = idx - l * N;
-                const double2 v = buf[(l >> 1) * N + PF::posB(pfa_makhoul(e, N))];
-                out[(i64)l * dline + e] = (l & 1) ? v.y : v.x;
-            }
-        }
-        // the next tile has landed when only this tile's stores are outstanding; one barrier then says both "every wave's
-        // pieces of the next tile are in LDS" and "this buffer is drained"
-        if (tile + stride < nTiles) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");
-        lds_barrier();
-        if (tile + 2 * stride < nTiles) dma(tile + 2 * stride, b);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct PfaPlan {
@@ -698,7 +547,6 @@ static void pfa_raise_lds() {
     PFA_RAISE((k_pfa_strided<D, P, T, 1, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 1, false>));
     PFA_RAISE((k_pfa_strided<D, P, T, 2, true>)); PFA_RAISE((k_pfa_strided<D, P, T, 2, false>));
     PFA_RAISE((k_pfa_axis0<D, S::P0, S::T0, false>)); PFA_RAISE((k_pfa_axis0<D, S::P0, S::T0, true>));
-    PFA_RAISE((k_pfa_axis0_pipe<D, S::P0, false>)); PFA_RAISE((k_pfa_axis0_pipe<D, S::P0, true>));
 #undef PFA_RAISE
 }
 
@@ -737,45 +585,17 @@ static void pfa_launch_axis0_pt(const PfaPlan *p, const double *src, double *dst
         hipLaunchKernelGGL((k_pfa_axis0<D, P, T, false>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
 }
 
-static bool pfa_pipe_enabled() {
-    static const bool on = !(getenv("DOTSOCP_PFA_PIPE") && atoi(getenv("DOTSOCP_PFA_PIPE")) == 0);
-    return on;
-}
-
-static int pfa_device_cus() {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-        v = 256;
-    return v;
-}
-
 template <int N>
 static void pfa_launch_axis0_n(const PfaPlan *p, const double *src, double *dst, i64 nLines, i64 sline, i64 dline,
                                int inverse, hipStream_t st) {
     typedef PfaShape<N> S;
     typedef typename S::D D;
-    // (measured and dropped: half the tile = twice the workgroups per CU along axis 0 -- Poisson solve 3.23 vs 3.26 ms at
-    // 1025 x 1025 x 129, 0.805 vs 0.796 ms at 513 x 513 x 129: these passes are not occupancy-bound)
-    if constexpr (N == 1025 || N == 513) {
-        constexpr int P = S::P0, LINES = 2 * P;
-        const i64 nTiles = nLines / LINES;
-        const int cus = pfa_device_cus();
-        if (pfa_pipe_enabled() && nTiles >= 2 * (i64)cus && nTiles < (1ll << 30) && (i64)LINES * sline * 8 <= PFA_PIPE_BUF &&
-            (i64)LINES * sline * 8 % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0)) {
-            const size_t lds = 2 * (size_t)PFA_PIPE_BUF + (size_t)(D::NH + 1) * sizeof(double2);
-            const i64 srcDoubles = nLines * sline;            // the array holds at least this much (pitched: whole rows)
-            if (inverse)
-                hipLaunchKernelGGL((k_pfa_axis0_pipe<D, P, true>), dim3((unsigned)cus), dim3(PFA_PIPE_T), lds, st, src, dst,
-                                   (int)nTiles, sline, dline, srcDoubles, p->ww, p->tab1, p->tab2);
-            else
-                hipLaunchKernelGGL((k_pfa_axis0_pipe<D, P, false>), dim3((unsigned)cus), dim3(PFA_PIPE_T), lds, st, src, dst,
-                                   (int)nTiles, sline, dline, srcDoubles, p->ww, p->tab1, p->tab2);
-            const i64 done = nTiles * LINES;                  // the lines left over: one small launch of the plain kernel
-            if (done < nLines)
-                pfa_launch_axis0_pt<D, S::P0, S::T0>(p, src + done * sline, dst + done * dline, nLines - done, sline, dline, inverse, st);
-            return;
-        }
-    }
+    // Measured and dropped (1025 x 1025 x 129 / 513 x 513 x 129, Poisson solve): half the tile = twice the workgroups per
+    // CU along axis 0: 3.26 vs 3.23 ms / 0.796 vs 0.805 ms; a persistent LDS-DMA pipeline like k_dct_axis0_pipe's (one
+    // workgroup per CU, two 72 KB buffers, counted vmcnt waits; correct, 66 / 66 operator tests): 3.43 vs 3.22 ms / 0.868
+    // vs 0.807 ms -- SLOWER.  These kernels are bound by their own vector-ALU work (folded DFT stages at 78 % / 64 % lane
+    // use, index arithmetic of the two maps), about 4.4 us per 65.6 KB tile against 1.8 us of multiply-adds at full lanes,
+    // not by bytes in flight: eight waves per CU hide less of it than sixteen.
     pfa_launch_axis0_pt<D, S::P0, S::T0>(p, src, dst, nLines, sline, dline, inverse, st);
 }
 
