@@ -118,9 +118,9 @@ int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom 
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
     dim3 blk(64, 4);
     switch (mode) {
-        case ACC_RAW: hipLaunchKernelGGL((k_acc_cone<ACC_RAW, 4>), grid, blk, 0, st, g, c, a); break;
-        case ACC_FUSED: hipLaunchKernelGGL((k_acc_cone<ACC_FUSED, 4>), grid, blk, 0, st, g, c, a); break;
-        case ACC_GATHER: hipLaunchKernelGGL((k_acc_cone<ACC_GATHER, 4>), grid, blk, 0, st, g, c, a); break;
+        case ACC_RAW: DS_KLAUNCH((k_acc_cone<ACC_RAW, 4>), grid, blk, 0, st, g, c, a); break;
+        case ACC_FUSED: DS_KLAUNCH((k_acc_cone<ACC_FUSED, 4>), grid, blk, 0, st, g, c, a); break;
+        case ACC_GATHER: DS_KLAUNCH((k_acc_cone<ACC_GATHER, 4>), grid, blk, 0, st, g, c, a); break;
         default: set_error("bad acc cone mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_acc_interp(double *__restrict__ x, cons
 int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
                       hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_acc_interp, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, xp, aux, n, k, mode,
+    DS_KLAUNCH(k_acc_interp, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, xp, aux, n, k, mode,
                        write_aux);
     DS_HIP(hipGetLastError());
     return 0;

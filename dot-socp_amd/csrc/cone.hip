@@ -53,11 +53,11 @@ int launch_proj_soc(double *out, const double *in, i64 M, i64 K, hipStream_t st)
     if (M <= 0) return 0;
     int blocks = launch_blocks(M, 256, 1 << 16);
     if (K == 10)
-        hipLaunchKernelGGL(k_proj_soc<10>, dim3(blocks), dim3(256), 0, st, out, in, M);
+        DS_KLAUNCH(k_proj_soc<10>, dim3(blocks), dim3(256), 0, st, out, in, M);
     else if (K == 6)
-        hipLaunchKernelGGL(k_proj_soc<6>, dim3(blocks), dim3(256), 0, st, out, in, M);
+        DS_KLAUNCH(k_proj_soc<6>, dim3(blocks), dim3(256), 0, st, out, in, M);
     else
-        hipLaunchKernelGGL(k_proj_soc_any, dim3(blocks), dim3(256), 0, st, out, in, M, K);
+        DS_KLAUNCH(k_proj_soc_any, dim3(blocks), dim3(256), 0, st, out, in, M, K);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd(Grid g, double *__restri
 
 int launch_bfd(const Grid &g, double *z, const double *q, double s, double dF, hipStream_t st) {
     if (g.Nz <= 0) return 0;
-    hipLaunchKernelGGL(k_bfd, cell_grid(g, g.ncl), dim3(TILE_Y, TILE_X), 0, st, g, z, q, s, s / sqrt(2.0), dF);
+    DS_KLAUNCH(k_bfd, cell_grid(g, g.ncl), dim3(TILE_Y, TILE_X), 0, st, g, z, q, s, s / sqrt(2.0), dF);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -128,9 +128,9 @@ int launch_bfd_conj(const Grid &g, double *q, const double *w, double s, hipStre
         return DOTSOCP_EINVAL;
     }
     const dim3 blk(TILE_Y, TILE_X);
-    if (g.Nz > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ncl), blk, 0, st, g, q, w, s, sf, 0, tail_bx, tail_by);
-    if (g.bxLayer > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ntl), blk, 0, st, g, q, w, s, sf, 1, tail_bx, tail_by);
-    if (g.byLayer > 0) hipLaunchKernelGGL(k_bfd_conj, cell_grid(g, g.ntl), blk, 0, st, g, q, w, s, sf, 2, tail_bx, tail_by);
+    if (g.Nz > 0) DS_KLAUNCH(k_bfd_conj, cell_grid(g, g.ncl), blk, 0, st, g, q, w, s, sf, 0, tail_bx, tail_by);
+    if (g.bxLayer > 0) DS_KLAUNCH(k_bfd_conj, cell_grid(g, g.ntl), blk, 0, st, g, q, w, s, sf, 1, tail_bx, tail_by);
+    if (g.byLayer > 0) DS_KLAUNCH(k_bfd_conj, cell_grid(g, g.ntl), blk, 0, st, g, q, w, s, sf, 2, tail_bx, tail_by);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -184,7 +184,7 @@ static inline dim3 march_grid(const Grid &g) {
 int launch_cone_proj(const Grid &g, const LoopCoef &c, const double *q, const double *beta, double *z,
                      hipStream_t st) {
     if (g.Nz <= 0) return 0;
-    hipLaunchKernelGGL(k_cone_march<0>, march_grid(g), dim3(TILE_Y, TILE_X), 0, st, g, c, q, (const double *)nullptr,
+    DS_KLAUNCH(k_cone_march<0>, march_grid(g), dim3(TILE_Y, TILE_X), 0, st, g, c, q, (const double *)nullptr,
                        beta, z, (double *)nullptr);
     DS_HIP(hipGetLastError());
     return 0;
@@ -193,7 +193,7 @@ int launch_cone_proj(const Grid &g, const LoopCoef &c, const double *q, const do
 int launch_beta_update(const Grid &g, const LoopCoef &c, const double *q, const double *z, double *beta,
                        hipStream_t st) {
     if (g.Nz <= 0) return 0;
-    hipLaunchKernelGGL(k_cone_march<1>, march_grid(g), dim3(TILE_Y, TILE_X), 0, st, g, c, q, z, (const double *)beta,
+    DS_KLAUNCH(k_cone_march<1>, march_grid(g), dim3(TILE_Y, TILE_X), 0, st, g, c, q, z, (const double *)beta,
                        (double *)nullptr, beta);
     DS_HIP(hipGetLastError());
     return 0;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_gather_tail(Grid g, const do
 int launch_gather_tail(const Grid &g, const double *z, const double *beta, double *tail_bx, double *tail_by,
                        hipStream_t st) {
     if (g.ncl <= 0) return 0;
-    hipLaunchKernelGGL(k_gather_tail, cell_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, z, beta, tail_bx, tail_by);
+    DS_KLAUNCH(k_gather_tail, cell_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, z, beta, tail_bx, tail_by);
     DS_HIP(hipGetLastError());
     return 0;
 }

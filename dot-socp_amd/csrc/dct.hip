@@ -1620,7 +1620,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
                 allow_big_lds(k_dct_tsolve_pipe<9>); allow_big_lds(k_dct_tsolve_pipe<10>);
             }
 #define TPIPE_LAUNCH(LGV)                                                                                              \
-    hipLaunchKernelGGL((k_dct_tsolve_pipe<LGV>), dim3((unsigned)G), dim3(TS_THREADS), ldsPipe, st, src, dst, map, nTiles, sa, \
+    DS_KLAUNCH((k_dct_tsolve_pipe<LGV>), dim3((unsigned)G), dim3(TS_THREADS), ldsPipe, st, src, dst, map, nTiles, sa, \
                        p->tw, p->ww)
             if (lg == 10) TPIPE_LAUNCH(10); else if (lg == 9) TPIPE_LAUNCH(9); else if (lg == 8) TPIPE_LAUNCH(8);
             else if (lg == 7) TPIPE_LAUNCH(7); else if (lg == 6) TPIPE_LAUNCH(6); else TPIPE_LAUNCH(5);
@@ -1648,7 +1648,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
             const size_t ntab = lg > 10 ? (size_t)(n >> 2) + (size_t)(n >> 1) + 1 : (size_t)(n >> 1) + (size_t)n;
             const size_t ldsPipe = (((size_t)2 << PIPE_LG_CPLX) + ntab) * sizeof(double2);
 #define SPIPE_LAUNCH(M, LGV)                                                                                         \
-    hipLaunchKernelGGL((k_dct_strided_pipe<M, LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, \
+    DS_KLAUNCH((k_dct_strided_pipe<M, LGV>), dim3((unsigned)G), dim3(PIPE_THREADS), ldsPipe, st, src, dst, map, \
                        nTiles, p->tw, p->ww)
             if (mode == 0) {
                 if (lg == 11) SPIPE_LAUNCH(0, 11); else if (lg == 10) SPIPE_LAUNCH(0, 10); else if (lg == 9) SPIPE_LAUNCH(0, 9);
@@ -1676,19 +1676,19 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
             const int lp2 = lp + 1;
             const unsigned blocks2 = (unsigned)((map.nLines + ((i64)2 << lp2) - 1) / ((i64)2 << lp2));
             if (mode == 0)
-                hipLaunchKernelGGL((k_dct_strided_wg<0, 1024>), dim3(blocks2), dim3(1024), lds2, st, src, dst, map, lg, lp2,
+                DS_KLAUNCH((k_dct_strided_wg<0, 1024>), dim3(blocks2), dim3(1024), lds2, st, src, dst, map, lg, lp2,
                                    p->tw, p->ww);
             else
-                hipLaunchKernelGGL((k_dct_strided_wg<1, 1024>), dim3(blocks2), dim3(1024), lds2, st, src, dst, map, lg, lp2,
+                DS_KLAUNCH((k_dct_strided_wg<1, 1024>), dim3(blocks2), dim3(1024), lds2, st, src, dst, map, lg, lp2,
                                    p->tw, p->ww);
             DS_HIP(hipGetLastError());
             return 0;
         }
         if (mode == 0)
-            hipLaunchKernelGGL((k_dct_strided_wg<0, 512>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
+            DS_KLAUNCH((k_dct_strided_wg<0, 512>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
                                p->tw, p->ww);
         else
-            hipLaunchKernelGGL((k_dct_strided_wg<1, 512>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
+            DS_KLAUNCH((k_dct_strided_wg<1, 512>), dim3(blocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map, lg, lp,
                                p->tw, p->ww);
         DS_HIP(hipGetLastError());
         return 0;
@@ -1697,7 +1697,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     do {                                                                                                       \
         static unsigned long long done = 0;                                                                    \
         if (DeviceOnce once_(done); once_) allow_big_lds(k_dct_strided<M, V>);                                    \
-        hipLaunchKernelGGL((k_dct_strided<M, V>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, lg, \
+        DS_KLAUNCH((k_dct_strided<M, V>), dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map, lg, \
                            lp, sa, p->tw, p->ww);                                                              \
     } while (0)
     if (mode == 0) { if (vec) LAUNCH_STRIDED(0, true); else LAUNCH_STRIDED(0, false); }
@@ -1760,7 +1760,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
     if (n == 1) {
         const i64 all = P0 * n1 * n2;                     // pad entries travel with the rows
         if (src != dst)
-            hipLaunchKernelGGL(k_copy, dim3(launch_blocks(all, 256, 1 << 14)), dim3(256), 0, st, src, dst, all);
+            DS_KLAUNCH(k_copy, dim3(launch_blocks(all, 256, 1 << 14)), dim3(256), 0, st, src, dst, all);
         DS_HIP(hipGetLastError());
         return 0;
     }
@@ -1818,7 +1818,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
                 const size_t ntab = lg > 10 ? (size_t)(n >> 2) + (size_t)(n >> 1) + 1 : (size_t)(n >> 1) + (size_t)n;
                 const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + ntab) * sizeof(double2);
 #define PIPE_LAUNCH(INV, LGV)                                                                                        \
-    hipLaunchKernelGGL((k_dct_axis0_pipe<INV, LGV>), dim3((unsigned)ncu), dim3(PIPE_THREADS), ldsPipe, st, src, dst, \
+    DS_KLAUNCH((k_dct_axis0_pipe<INV, LGV>), dim3((unsigned)ncu), dim3(PIPE_THREADS), ldsPipe, st, src, dst, \
                        (int)nTiles, p->tw, p->ww)
                 if (inverse) {
                     if (lg == 11) PIPE_LAUNCH(true, 11); else if (lg == 10) PIPE_LAUNCH(true, 10); else if (lg == 9) PIPE_LAUNCH(true, 9);
@@ -1837,19 +1837,19 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             const int lrows = lrw + 2;
             const unsigned wblocks = (unsigned)((((map.nLines + 1) / 2) + ((i64)1 << lrows) - 1) >> lrows);
             if (inverse)
-                hipLaunchKernelGGL(k_dct_axis0_wg<true>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
+                DS_KLAUNCH(k_dct_axis0_wg<true>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
                                    lg, lrows, p->tw, p->ww);
             else
-                hipLaunchKernelGGL(k_dct_axis0_wg<false>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
+                DS_KLAUNCH(k_dct_axis0_wg<false>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
                                    lg, lrows, p->tw, p->ww);
             DS_HIP(hipGetLastError());
             return 0;
         }
         if (inverse)
-            hipLaunchKernelGGL(k_dct_axis0<true>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
+            DS_KLAUNCH(k_dct_axis0<true>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
                                p->tw, p->ww);
         else
-            hipLaunchKernelGGL(k_dct_axis0<false>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
+            DS_KLAUNCH(k_dct_axis0<false>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
                                p->tw, p->ww);
     } else {
         // DOTSOCP_PFA=0: the dense product also for the lengths that have a prime-factor transform
@@ -1874,12 +1874,12 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             const unsigned lt = (unsigned)((map.nLines + MF_LT - 1) / MF_LT);
             if (inverse) {
                 dim3 grid((unsigned)((p->njE + MF_KT - 1) / MF_KT), lt, 1);
-                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma_split<true, 8, true>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
-                else hipLaunchKernelGGL((k_dct_mfma_split<false, 8, true>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+                if (axis == 0) DS_KLAUNCH((k_dct_mfma_split<true, 8, true>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+                else DS_KLAUNCH((k_dct_mfma_split<false, 8, true>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
             } else {
                 dim3 grid((unsigned)((p->ne + MF_KT - 1) / MF_KT), lt, 2);
-                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma_split<true, 8, false>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
-                else hipLaunchKernelGGL((k_dct_mfma_split<false, 8, false>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+                if (axis == 0) DS_KLAUNCH((k_dct_mfma_split<true, 8, false>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
+                else DS_KLAUNCH((k_dct_mfma_split<false, 8, false>), grid, dim3(256), 0, st, src, dst, map, (int)n, sp);
             }
             DS_HIP(hipGetLastError());
             return 0;
@@ -1889,11 +1889,11 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             dim3 grid((unsigned)((n + MF_KT - 1) / MF_KT), (unsigned)((map.nLines + MF_LT - 1) / MF_LT));
             static const int kc = getenv("DOTSOCP_MFMA_KC") ? atoi(getenv("DOTSOCP_MFMA_KC")) : 8;
             if (kc == 8) {
-                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma<true, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-                else hipLaunchKernelGGL((k_dct_mfma<false, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+                if (axis == 0) DS_KLAUNCH((k_dct_mfma<true, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+                else DS_KLAUNCH((k_dct_mfma<false, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
             } else {
-                if (axis == 0) hipLaunchKernelGGL((k_dct_mfma<true, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-                else hipLaunchKernelGGL((k_dct_mfma<false, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+                if (axis == 0) DS_KLAUNCH((k_dct_mfma<true, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+                else DS_KLAUNCH((k_dct_mfma<false, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
             }
             DS_HIP(hipGetLastError());
             return 0;
@@ -1906,10 +1906,10 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         const double *M = inverse ? p->Cinv : p->Cfwd;
         if (axis != 0) {
             const int KC = DCT_THREADS / TL;
-            hipLaunchKernelGGL((k_dct_dense<true>), dim3(bx, (unsigned)((n + KC - 1) / KC)), dim3(DCT_THREADS), lds, st, src,
+            DS_KLAUNCH((k_dct_dense<true>), dim3(bx, (unsigned)((n + KC - 1) / KC)), dim3(DCT_THREADS), lds, st, src,
                                dst, map, (int)n, TL, M);
         } else {
-            hipLaunchKernelGGL((k_dct_dense<false>), dim3(bx, (unsigned)((n + DCT_THREADS - 1) / DCT_THREADS)),
+            DS_KLAUNCH((k_dct_dense<false>), dim3(bx, (unsigned)((n + DCT_THREADS - 1) / DCT_THREADS)),
                                dim3(DCT_THREADS), lds, st, src, dst, map, (int)n, TL, M);
         }
     }
@@ -1951,7 +1951,7 @@ int launch_spectral_divide_pencil(double *data, i64 ny, i64 nplane, i64 line0, i
     (void)nplane;
     if (nl * nt <= 0) return 0;
     dim3 grid((unsigned)((nl + 255) / 256), (unsigned)nt);
-    hipLaunchKernelGGL(k_spectral_divide_pencil, grid, dim3(256), 0, st, data, ny, line0, nl, nt, kscale, cy, cx, ct);
+    DS_KLAUNCH(k_spectral_divide_pencil, grid, dim3(256), 0, st, data, ny, line0, nl, nt, kscale, cy, cx, ct);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -1961,7 +1961,7 @@ int launch_spectral_divide(double *data, i64 ny, i64 nx, i64 nt, i64 x0, i64 nxl
     (void)nx;
     if (ny * nxl * nt <= 0) return 0;
     dim3 grid((unsigned)((ny + 63) / 64), (unsigned)((nxl + 3) / 4), (unsigned)nt);
-    hipLaunchKernelGGL(k_spectral_divide, grid, dim3(64, 4), 0, st, data, ny, pitch0 > ny ? pitch0 : ny, nxl, nt, x0, kscale, cy, cx, ct);
+    DS_KLAUNCH(k_spectral_divide, grid, dim3(64, 4), 0, st, data, ny, pitch0 > ny ? pitch0 : ny, nxl, nt, x0, kscale, cy, cx, ct);
     DS_HIP(hipGetLastError());
     return 0;
 }

@@ -163,11 +163,11 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(64, 4);
     switch (mode) {
-        case 0: hipLaunchKernelGGL((k_cone_fused<0, 4>), grid, blk, 0, st, g, c, a); break;
-        case 1: hipLaunchKernelGGL((k_cone_fused<1, 4>), grid, blk, 0, st, g, c, a); break;
-        case 2: hipLaunchKernelGGL((k_cone_fused<2, 4>), grid, blk, 0, st, g, c, a); break;
-        case 3: hipLaunchKernelGGL((k_cone_fused<3, 4>), grid, blk, 0, st, g, c, a); break;
-        case 4: hipLaunchKernelGGL((k_cone_fused<4, 4>), grid, blk, 0, st, g, c, a); break;
+        case 0: DS_KLAUNCH((k_cone_fused<0, 4>), grid, blk, 0, st, g, c, a); break;
+        case 1: DS_KLAUNCH((k_cone_fused<1, 4>), grid, blk, 0, st, g, c, a); break;
+        case 2: DS_KLAUNCH((k_cone_fused<2, 4>), grid, blk, 0, st, g, c, a); break;
+        case 3: DS_KLAUNCH((k_cone_fused<3, 4>), grid, blk, 0, st, g, c, a); break;
+        case 4: DS_KLAUNCH((k_cone_fused<4, 4>), grid, blk, 0, st, g, c, a); break;
         default: set_error("bad fused mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "solver.h"
+#include "defer.h"
 
 namespace dotsocp {
 
@@ -61,7 +62,7 @@ void stream_stress(hipStream_t st) {
     }
     if ((state & 3) == 0) return;                                          // a quarter of the calls add nothing
     const long long ticks = (long long)((state >> 8) % 30000);             // up to 300 us at 100 MHz
-    hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, st, ticks);
+    DS_KLAUNCH(k_stall, dim3(1), dim3(64), 0, st, ticks);
 }
 
 bool canary_enabled() {
@@ -81,9 +82,9 @@ int guarded_malloc(void **p, size_t bytes) {
     // the slack between the payload's end and the rear band is pattern too: an overrun by one element is seen
     const size_t head = GUARD / 8, tail = (padded - bytes + GUARD) / 8;
     (void)hipGetLastError();       // a stale error of an earlier, failed call must not be blamed on the fill launches
-    hipLaunchKernelGGL(k_fill_pattern, dim3(4), dim3(256), 0, nullptr, (unsigned long long *)base, head);
+    DS_KLAUNCH(k_fill_pattern, dim3(4), dim3(256), 0, nullptr, (unsigned long long *)base, head);
     // payload sizes are multiples of 8 (doubles, double2); the tail starts right behind the payload
-    hipLaunchKernelGGL(k_fill_pattern, dim3(4), dim3(256), 0, nullptr, (unsigned long long *)(base + GUARD + bytes / 8 * 8),
+    DS_KLAUNCH(k_fill_pattern, dim3(4), dim3(256), 0, nullptr, (unsigned long long *)(base + GUARD + bytes / 8 * 8),
                        tail);
     DS_HIP(hipGetLastError());
     DS_HIP(hipDeviceSynchronize());

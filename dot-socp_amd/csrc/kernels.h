@@ -1,6 +1,7 @@
 // Host-side launchers of the gfx950 kernels (definitions in *.hip).
 #pragma once
 #include "common.h"
+#include "defer.h"
 
 namespace dotsocp {
 

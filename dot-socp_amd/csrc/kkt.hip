@@ -579,7 +579,7 @@ int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double 
     const dim3 blk(TILE_Y, TILE_X);
 #define KKT_PART(W, P, slot)                                                                                     \
     if (parts & P)                                                                                               \
-    hipLaunchKernelGGL((k_kkt<W, P>), grid, blk, 0, st, g, c, k, chunk, phi, q, alpha, z, beta, cvec, weight, halo, \
+    DS_KLAUNCH((k_kkt<W, P>), grid, blk, 0, st, g, c, k, chunk, phi, q, alpha, z, beta, cvec, weight, halo, \
                        w.partials + ((layer0 && (slot) > 0 ? (slot) - 1 : (slot)) + base) * region * S_COUNT,    \
                        (P == 1) ? resid : nullptr)
     if (weight) { KKT_PART(true, 1, 0); KKT_PART(true, 2, 1); KKT_PART(true, 4, 2); KKT_PART(true, 8, 3); }
@@ -602,20 +602,20 @@ int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, 
     double *part = w.partials + 1 * region * S_COUNT;
     const dim3 blk(TILE_Y, TILE_X);
     if (!edges) {
-        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, false>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-        else hipLaunchKernelGGL((k_kkt_cells<false, false>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        if (weight) DS_KLAUNCH((k_kkt_cells<true, false>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        else DS_KLAUNCH((k_kkt_cells<false, false>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
         DS_HIP(hipGetLastError());
         return 0;
     }
-    if (weight) hipLaunchKernelGGL((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-    else hipLaunchKernelGGL((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    if (weight) DS_KLAUNCH((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    else DS_KLAUNCH((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
     DS_HIP(hipGetLastError());
     for (int dir = 0; dir < 2; ++dir) {
         const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;
         if (len <= 0 || lines <= 0) continue;
         dim3 gb((unsigned)((len + 255) / 256), (unsigned)lines, (unsigned)((g.ntl + BND_TC - 1) / BND_TC));
         double *pb = w.partials + (2 + dir) * region * S_COUNT;
-#define BND(W, D) hipLaunchKernelGGL((k_kkt_bnd<W, D>), gb, dim3(256), 0, st, g, c, k, fg, q_new, alpha, weight, a.q2, a.sx, a.sy, pb)
+#define BND(W, D) DS_KLAUNCH((k_kkt_bnd<W, D>), gb, dim3(256), 0, st, g, c, k, fg, q_new, alpha, weight, a.q2, a.sx, a.sy, pb)
         if (weight) { if (dir == 0) BND(true, 0); else BND(true, 1); }
         else { if (dir == 0) BND(false, 0); else BND(false, 1); }
 #undef BND
@@ -633,8 +633,8 @@ int launch_norms(const Grid &g, const LoopCoef &c, const KktCoef &k, const Fused
     if (g.Nz > 0) {
         dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
         double *part = w.partials + 1 * region * S_COUNT;
-        if (weight) hipLaunchKernelGGL((k_kkt_cells<true, false, true>), grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
-        else hipLaunchKernelGGL((k_kkt_cells<false, false, true>), grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
+        if (weight) DS_KLAUNCH((k_kkt_cells<true, false, true>), grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
+        else DS_KLAUNCH((k_kkt_cells<false, false, true>), grid, dim3(TILE_Y, TILE_X), 0, st, g, c, k, a, phi, alpha, weight, part);
     }
     // q-layout arrays: q0 cells, then the owned bx and by layers (a slab's halo layers are not its own)
     struct R { const double *x; i64 n; int slot, reg; };
@@ -647,7 +647,7 @@ int launch_norms(const Grid &g, const LoopCoef &c, const KktCoef &k, const Fused
         i64 blocks = (r.n + 256 * 64 - 1) / (256 * 64);
         if (blocks > region) blocks = region;
         double *part = w.partials + r.reg * region * S_COUNT;
-        hipLaunchKernelGGL(k_sumsq, dim3((unsigned)blocks), dim3(256), 0, st, r.x, r.n, r.slot, part);
+        DS_KLAUNCH(k_sumsq, dim3((unsigned)blocks), dim3(256), 0, st, r.x, r.n, r.slot, part);
     }
     DS_HIP(hipGetLastError());
     return 0;
@@ -660,9 +660,9 @@ double *kkt_qstep_partials(const Grid &g, const KktWork &w) {
 
 int launch_kkt_final(const Grid &g, const KktWork &w, hipStream_t st) {
     // w.sums: [S_COUNT] result followed by [KKT_SLICES][S_COUNT] intermediate sums
-    hipLaunchKernelGGL(k_kkt_final, dim3(S_COUNT, KKT_SLICES), dim3(256), 0, st, w.partials,
+    DS_KLAUNCH(k_kkt_final, dim3(S_COUNT, KKT_SLICES), dim3(256), 0, st, w.partials,
                        KKT_REGIONS * kkt_region_blocks(g), w.sums + S_COUNT);
-    hipLaunchKernelGGL(k_kkt_final2, dim3(1), dim3(64), 0, st, w.sums + S_COUNT, KKT_SLICES, w.sums);
+    DS_KLAUNCH(k_kkt_final2, dim3(1), dim3(64), 0, st, w.sums + S_COUNT, KKT_SLICES, w.sums);
     DS_HIP(hipGetLastError());
     return 0;
 }

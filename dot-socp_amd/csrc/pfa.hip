@@ -567,7 +567,7 @@ static void pfa_launch_strided_n(const PfaPlan *p, const double *src, double *ds
     typedef typename S::D D;
     constexpr int P = S::P, T = S::T;
     const size_t lds = (size_t)P * N * sizeof(double2);
-#define PFA_GO(M, V) hipLaunchKernelGGL((k_pfa_strided<D, P, T, M, V>), dim3(blocks), dim3(T), lds, st, src, dst, g, sa, p->ww, p->tab1, p->tab2)
+#define PFA_GO(M, V) DS_KLAUNCH((k_pfa_strided<D, P, T, M, V>), dim3(blocks), dim3(T), lds, st, src, dst, g, sa, p->ww, p->tab1, p->tab2)
     if (mode == 0) { if (vec) PFA_GO(0, true); else PFA_GO(0, false); }
     else if (mode == 1) { if (vec) PFA_GO(1, true); else PFA_GO(1, false); }
     else { if (vec) PFA_GO(2, true); else PFA_GO(2, false); }
@@ -580,9 +580,9 @@ static void pfa_launch_axis0_pt(const PfaPlan *p, const double *src, double *dst
     const size_t lds = (size_t)P * D::N * sizeof(double2);
     const unsigned blocks = (unsigned)((nLines + 2 * P - 1) / (2 * P));
     if (inverse)
-        hipLaunchKernelGGL((k_pfa_axis0<D, P, T, true>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
+        DS_KLAUNCH((k_pfa_axis0<D, P, T, true>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
     else
-        hipLaunchKernelGGL((k_pfa_axis0<D, P, T, false>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
+        DS_KLAUNCH((k_pfa_axis0<D, P, T, false>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
 }
 
 template <int N>

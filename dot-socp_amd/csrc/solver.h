@@ -2,6 +2,7 @@
 #pragma once
 #include <chrono>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -131,6 +132,9 @@ struct Solver {
     int fork_z();                      // every slab's second stream starts behind what its main stream holds so far
     bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process
+    // one host thread per slab issues that slab's launches while run() is active (defer.h); null: the caller's thread
+    // issues everything (one slab, one process per GPU, DOTSOCP_HOST_THREADS=0)
+    std::unique_ptr<DeferCtx> defer;
     int world = 1;                  // total number of slabs
     int rank = 0;                   // RCCL mode: this process's slab
     void *nccl = nullptr;           // ncclComm_t when a communicator is attached

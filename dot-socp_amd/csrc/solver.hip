@@ -50,12 +50,12 @@ int Solver::use(const Slab &s) {
 int Solver::sync_all() {
     for (auto &s : slabs) {
         DS_CHECK(use(s));
-        if (s.st_z) DS_HIP(hipStreamSynchronize(s.st_z));
-        if (s.st) DS_HIP(hipStreamSynchronize(s.st));
+        if (s.st_z) DS_HIP(ds_stream_synchronize(s.st_z));
+        if (s.st) DS_HIP(ds_stream_synchronize(s.st));
     }
     if (slabs.empty() && stream) {
         DS_CHECK(use_dev(device));
-        DS_HIP(hipStreamSynchronize(stream));
+        DS_HIP(ds_stream_synchronize(stream));
     }
     return 0;
 }
@@ -72,19 +72,19 @@ int Solver::xcopy(Slab &from, const double *src, Slab &to, double *dst, i64 coun
     const size_t bytes = sizeof(double) * (size_t)count;
     if (from.st == to.st) {
         DS_CHECK(use(to));
-        DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
+        DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
         return 0;
     }
     hipEvent_t a = next_xev(from), b = next_xev(to);
     DS_CHECK(use(from));
-    DS_HIP(hipEventRecord(a, from.st));
+    DS_HIP(ds_event_record(a, from.st));
     DS_CHECK(use(to));
-    DS_HIP(hipStreamWaitEvent(to.st, a, 0));
-    if (from.dev == to.dev) DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
-    else DS_HIP(hipMemcpyPeerAsync(dst, to.dev, src, from.dev, bytes, to.st));
-    DS_HIP(hipEventRecord(b, to.st));
+    DS_HIP(ds_stream_wait_event(to.st, a, 0));
+    if (from.dev == to.dev) DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
+    else DS_HIP(ds_memcpy_peer_async(dst, to.dev, src, from.dev, bytes, to.st));
+    DS_HIP(ds_event_record(b, to.st));
     DS_CHECK(use(from));
-    DS_HIP(hipStreamWaitEvent(from.st, b, 0));
+    DS_HIP(ds_stream_wait_event(from.st, b, 0));
     return 0;
 }
 
@@ -93,33 +93,33 @@ int Solver::xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, doub
     if (width == 0 || height == 0) return 0;
     if (from.st == to.st) {
         DS_CHECK(use(to));
-        DS_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+        DS_HIP(ds_memcpy2d_async(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
         return 0;
     }
     hipEvent_t a = next_xev(from), b = next_xev(to);
     DS_CHECK(use(from));
-    DS_HIP(hipEventRecord(a, from.st));
+    DS_HIP(ds_event_record(a, from.st));
     DS_CHECK(use(to));
-    DS_HIP(hipStreamWaitEvent(to.st, a, 0));
+    DS_HIP(ds_stream_wait_event(to.st, a, 0));
     if (from.dev == to.dev || peer_ok) {
         // different devices: peer access was enabled in both directions when the slabs were placed (alloc_slabs)
-        DS_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+        DS_HIP(ds_memcpy2d_async(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
     } else {
         // peer access refused: row by row through hipMemcpyPeerAsync, which stages through the host by itself
         for (size_t r = 0; r < height; ++r)
-            DS_HIP(hipMemcpyPeerAsync((char *)dst + r * dpitch, to.dev, (const char *)src + r * spitch, from.dev, width, to.st));
+            DS_HIP(ds_memcpy_peer_async((char *)dst + r * dpitch, to.dev, (const char *)src + r * spitch, from.dev, width, to.st));
     }
-    DS_HIP(hipEventRecord(b, to.st));
+    DS_HIP(ds_event_record(b, to.st));
     DS_CHECK(use(from));
-    DS_HIP(hipStreamWaitEvent(from.st, b, 0));
+    DS_HIP(ds_stream_wait_event(from.st, b, 0));
     return 0;
 }
 
 // second streams: fork behind everything enqueued on the slab's main stream ...
 int Solver::fork_z() {
     FOR_SLABS(s) {
-        DS_HIP(hipEventRecord(s.ev_fork, s.st));
-        DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
+        DS_HIP(ds_event_record(s.ev_fork, s.st));
+        DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
     }
     return 0;
 }
@@ -146,10 +146,11 @@ DevRes *Solver::res_for(int dev) {
 }
 
 void Solver::free_slabs() {
+    defer.reset();                   // joins the slab threads (their queues are empty outside run())
     for (auto &s : slabs) {
         (void)use(s);
-        if (s.st_z) (void)hipStreamSynchronize(s.st_z);
-        if (s.st) (void)hipStreamSynchronize(s.st);
+        if (s.st_z) (void)ds_stream_synchronize(s.st_z);
+        if (s.st) (void)ds_stream_synchronize(s.st);
         for (auto &e : s.xev) if (e) (void)hipEventDestroy(e);
         if (s.ev_tri) (void)hipEventDestroy(s.ev_tri);
         if (s.ev_msg) (void)hipEventDestroy(s.ev_msg);
@@ -398,6 +399,23 @@ int Solver::alloc_slabs(int first, int count) {
                 if (e != hipErrorPeerAccessAlreadyEnabled) peer_ok = false;
             }
         }
+    // several slabs in this process: one issuing thread per slab (defer.h).  Default: on when the slabs live on DIFFERENT
+    // devices (what a single MATLAB process with opts.ngpu drives: every device has its own submission queue), off when
+    // they share one -- measured there, 8 slabs: 1.26 vs 1.06-1.17 ms per iteration on a 64^3 grid (the threads contend
+    // for the one device's queue and add hand-off latency), 14.1 vs 14.9 ms at 1024 x 1024 x 128.
+    // DOTSOCP_HOST_THREADS=0 / 1 overrides
+    {
+        const char *e = getenv("DOTSOCP_HOST_THREADS");
+        const bool want = e ? (atoi(e) != 0) : (multi_device && cross_device);
+        if (want && count > 1 && !remote()) {
+            defer.reset(new DeferCtx());
+            for (auto &s : slabs) {
+                const int w = defer->add_worker(s.dev);
+                defer->map_stream(s.st, w);
+                defer->map_stream(s.st_z, w);
+            }
+        }
+    }
     return 0;
 }
 
@@ -425,14 +443,14 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     rank = rk;
     if (!getenv("DOTSOCP_OVERLAP")) overlap = wd > 1;
     DS_CHECK(ensure_alloc());
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_HIP(ds_stream_synchronize(stream));
     if (wd > 1) {
         // handshake: the communicator spans `wd` ranks and the neighbours are the ranks this slab expects (also opens
         // the neighbour connections before the first timed iteration)
         double h[4] = {1.0, (double)rk, 0.0, -1.0};
         double *d = nullptr;
         DS_CHECK(dmalloc(&d, 4));
-        DS_HIP(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, stream));
+        DS_HIP(ds_memcpy_async(d, h, sizeof h, hipMemcpyHostToDevice, stream));
         DS_NCCL(api.AllReduce(d, d + 2, 1, ncclDouble, ncclSum, comm, stream));
         DS_NCCL(api.GroupStart());
         ++open_groups;
@@ -440,8 +458,8 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
         if (rk > 0) DS_NCCL_G(api.Recv(d + 3, 1, ncclDouble, rk - 1, comm, stream));
         --open_groups;
         DS_NCCL(api.GroupEnd());
-        DS_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, stream));
-        DS_HIP(hipStreamSynchronize(stream));
+        DS_HIP(ds_memcpy_async(h, d, sizeof h, hipMemcpyDeviceToHost, stream));
+        DS_HIP(ds_stream_synchronize(stream));
         dfree(d);
         if (h[2] != (double)wd || (rk > 0 && h[3] != (double)(rk - 1))) {
             set_error("RCCL handshake failed: %g ranks answered (expected %d), left neighbour says %g (expected %d)", h[2], wd,
@@ -542,7 +560,7 @@ int Solver::flush_msgs() {
     for (size_t i = 0; i < P; ++i)
         if (sends[i]) {
             DS_CHECK(use(slabs[i]));
-            DS_HIP(hipEventRecord(slabs[i].ev_msg, slabs[i].st));
+            DS_HIP(ds_event_record(slabs[i].ev_msg, slabs[i].st));
         }
     for (size_t t = 0; t < P; ++t) {
         if (!gets[t]) continue;
@@ -554,7 +572,7 @@ int Solver::flush_msgs() {
         for (const Msg &m : msgs) {
             if (m.to != (int)t || m.count <= 0) continue;
             if (!waited[m.from] && slabs[m.from].st != to.st) {
-                DS_HIP(hipStreamWaitEvent(to.st, slabs[m.from].ev_msg, 0));
+                DS_HIP(ds_stream_wait_event(to.st, slabs[m.from].ev_msg, 0));
                 waited[m.from] = 1;
             }
             if (g.n == DS_MAX_WORLD) {
@@ -565,7 +583,7 @@ int Solver::flush_msgs() {
             ++g.n;
         }
         DS_CHECK(launch_gather_msgs(g, to.st));
-        DS_HIP(hipEventRecord(to.ev_got, to.st));
+        DS_HIP(ds_event_record(to.ev_got, to.st));
     }
     for (size_t f = 0; f < P; ++f) {
         if (!sends[f]) continue;
@@ -574,7 +592,7 @@ int Solver::flush_msgs() {
         std::vector<char> waited(P, 0);
         for (const Msg &m : msgs)
             if (m.from == (int)f && m.count > 0 && !waited[m.to] && slabs[m.to].st != from.st) {
-                DS_HIP(hipStreamWaitEvent(from.st, slabs[m.to].ev_got, 0));
+                DS_HIP(ds_stream_wait_event(from.st, slabs[m.to].ev_got, 0));
                 waited[m.to] = 1;
             }
     }
@@ -659,7 +677,7 @@ int Solver::transpose(bool forward) {
         if (s.nl <= 0) return 0;
         double *st_ = s.stage + off[rank], *pe = s.pencil + s.nl * pt0[rank];
         const size_t bytes = sizeof(double) * (size_t)(s.nl * s.g.ntl);
-        DS_HIP(hipMemcpyAsync(fwd ? pe : st_, fwd ? st_ : pe, bytes, hipMemcpyDeviceToDevice, stream));
+        DS_HIP(ds_memcpy_async(fwd ? pe : st_, fwd ? st_ : pe, bytes, hipMemcpyDeviceToDevice, stream));
         return 0;
     };
     if (forward) {
@@ -740,12 +758,12 @@ int Solver::tri_exchange(bool back) {
         // overwrites its message only behind its own next gather, which waits for every receiver of this one.
         const bool gather = pull_default("DOTSOCP_TRI_GATHER");
         if (gather) {
-            FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_tri, s.st));
+            FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, s.st));
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
                 GatherMsgs m{};
                 m.n = 0;
                 for (auto &ss : slabs) {    // sender
-                    if (ss.st != sd.st) DS_HIP(hipStreamWaitEvent(sd.st, ss.ev_tri, 0));
+                    if (ss.st != sd.st) DS_HIP(ds_stream_wait_event(sd.st, ss.ev_tri, 0));
                     const int d = sd.index, q = ss.index;
                     if (!back) {            // slab q's message for owner d
                         m.src[m.n] = ss.tri_send + off(d);
@@ -777,7 +795,7 @@ int Solver::tri_exchange(bool back) {
     {
         double *a = s.tri_send + off(rank), *b = s.tri_recv + (i64)rank * cnt(rank);
         if (back) { a = s.tri_bsend + (i64)rank * cnt(rank); b = s.tri_brecv + off(rank); }
-        DS_HIP(hipMemcpyAsync(b, a, sizeof(double) * (size_t)cnt(rank), hipMemcpyDeviceToDevice, stream));
+        DS_HIP(ds_memcpy_async(b, a, sizeof(double) * (size_t)cnt(rank), hipMemcpyDeviceToDevice, stream));
     }
     DS_NCCL(api.GroupStart());
     ++open_groups;
@@ -841,13 +859,13 @@ i64 Solver::field_len(int field) const {
 int Solver::copy_rows(double *dev, double *host, i64 rowlen, i64 pitch, i64 nrows, bool up, hipStream_t st) {
     if (rowlen <= 0 || nrows <= 0) return 0;
     if (pitch == rowlen) {
-        if (up) DS_HIP(hipMemcpyAsync(dev, host, sizeof(double) * rowlen * nrows, hipMemcpyHostToDevice, st));
-        else DS_HIP(hipMemcpyAsync(host, dev, sizeof(double) * rowlen * nrows, hipMemcpyDeviceToHost, st));
+        if (up) DS_HIP(ds_memcpy_async(dev, host, sizeof(double) * rowlen * nrows, hipMemcpyHostToDevice, st));
+        else DS_HIP(ds_memcpy_async(host, dev, sizeof(double) * rowlen * nrows, hipMemcpyDeviceToHost, st));
         return 0;
     }
-    if (up) DS_HIP(hipMemcpy2DAsync(dev, sizeof(double) * pitch, host, sizeof(double) * rowlen, sizeof(double) * rowlen,
+    if (up) DS_HIP(ds_memcpy2d_async(dev, sizeof(double) * pitch, host, sizeof(double) * rowlen, sizeof(double) * rowlen,
                                     (size_t)nrows, hipMemcpyHostToDevice, st));
-    else DS_HIP(hipMemcpy2DAsync(host, sizeof(double) * rowlen, dev, sizeof(double) * pitch, sizeof(double) * rowlen,
+    else DS_HIP(ds_memcpy2d_async(host, sizeof(double) * rowlen, dev, sizeof(double) * pitch, sizeof(double) * rowlen,
                                  (size_t)nrows, hipMemcpyDeviceToHost, st));
     return 0;
 }
@@ -880,7 +898,7 @@ static int copy_field(Solver &S, int field, double *host, bool up) {
             case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
                 double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
                 const int K = S.prob.dim == 1 ? 6 : 10;
-                if (up && S.prob.dim == 1) DS_HIP(hipMemsetAsync(d, 0, sizeof(double) * 10 * g.Nz, cur));
+                if (up && S.prob.dim == 1) DS_HIP(ds_memset_async(d, 0, sizeof(double) * 10 * g.Nz, cur));
                 for (int j = 0; j < K; ++j) {
                     const int pj = S.prob.dim == 1 ? k1dCols[j] : j;
                     DS_CHECK(nodes(d + pj * g.Nz, host + j * NzG + hplane * t0, g.ncl));
@@ -942,7 +960,7 @@ void Solver::prof_begin(int phase, bool on_z) {
     };
     p.a = get();
     p.b = get();
-    (void)hipEventRecord(p.a, st);
+    (void)ds_event_record(p.a, st);
     pending.push_back(p);
 }
 
@@ -951,14 +969,14 @@ void Solver::prof_end(int phase, bool on_z) {
     (void)use_dev(device);
     hipStream_t st = on_z ? stream_z : stream;
     for (auto it2 = pending.rbegin(); it2 != pending.rend(); ++it2)
-        if (it2->phase == phase) { (void)hipEventRecord(it2->b, st); break; }
+        if (it2->phase == phase) { (void)ds_event_record(it2->b, st); break; }
 }
 
 int Solver::prof_flush() {
     if (!profiling || pending.empty()) return 0;
     DS_CHECK(use_dev(device));
-    DS_HIP(hipStreamSynchronize(stream_z));
-    DS_HIP(hipStreamSynchronize(stream));
+    DS_HIP(ds_stream_synchronize(stream_z));
+    DS_HIP(ds_stream_synchronize(stream));
     for (auto &p : pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -1118,8 +1136,8 @@ int Solver::begin(const dotsocp_opts *o) {
         Slab &s0 = slabs[0];
         DS_CHECK(use(s0));
         const double v = 1.0;
-        DS_HIP(hipMemcpyAsync(s0.c + s0.g.Nphi, &v, sizeof v, hipMemcpyHostToDevice, s0.st));
-        DS_HIP(hipStreamSynchronize(s0.st));
+        DS_HIP(ds_memcpy_async(s0.c + s0.g.Nphi, &v, sizeof v, hipMemcpyHostToDevice, s0.st));
+        DS_HIP(ds_stream_synchronize(s0.st));
     }
     begun = true;
     elapsed_prev = 0.0;
@@ -1319,7 +1337,7 @@ int Solver::phase_q(int part, bool kkt) {
     if (fused && qrhs) apend = false;        // the q-step wrote the scaled alpha into the ping-pong partner
     prof_end(PH_QSTEP);
     if (part == 2) {                                                    // the middle chunks (second streams)
-        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
+        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.ev_join, 0));
     }
     rhs_valid = fused && qrhs;
     // the halo exchange waits for the next consumer: the next step() runs it beside the first cone chunks
@@ -1397,7 +1415,7 @@ int Solver::kkt_sums(double *S, bool folded) {
         // the launches below write per-workgroup partial sums into four regions; grids of different
         // shapes may use a region on different calls, so stale entries are cleared first
         FOR_SLABS(s)
-            DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+            DS_HIP(ds_memset_async(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
     }
     // ---- cell part (region 1 of the partial sums) ----
     int rest = folded ? 0 : (1 | 4 | 8);
@@ -1458,11 +1476,11 @@ int Solver::reduce_sums(double *S) {
     FOR_SLABS(s) {
         DS_CHECK(launch_kkt_final(s.g, s.kw, s.st));
         if (remote()) break;
-        DS_HIP(hipMemcpyAsync(s.h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s.st));
+        DS_HIP(ds_memcpy_async(s.h_sums, s.kw.sums, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s.st));
     }
     if (!remote()) {        // all slabs are enqueued before the host waits for the first; summed in slab order
         FOR_SLABS(s) {
-            DS_HIP(hipStreamSynchronize(s.st));
+            DS_HIP(ds_stream_synchronize(s.st));
             for (int i = 0; i < S_COUNT; ++i) S[i] += s.h_sums[i];
         }
     }
@@ -1473,10 +1491,10 @@ int Solver::reduce_sums(double *S) {
         Slab &s = slabs[0];
         DS_NCCL(api.AllReduce(s.kw.sums, d_red, S_COUNT, ncclDouble, ncclSum, (ncclComm_t)nccl, stream));
         h_sums[S_COUNT] = S[S_COUNT];
-        DS_HIP(hipMemcpyAsync(d_red + S_COUNT, h_sums + S_COUNT, sizeof(double), hipMemcpyHostToDevice, stream));
+        DS_HIP(ds_memcpy_async(d_red + S_COUNT, h_sums + S_COUNT, sizeof(double), hipMemcpyHostToDevice, stream));
         DS_NCCL(api.AllReduce(d_red + S_COUNT, d_red + S_COUNT, 1, ncclDouble, ncclMax, (ncclComm_t)nccl, stream));
-        DS_HIP(hipMemcpyAsync(h_sums, d_red, sizeof(double) * (S_COUNT + 1), hipMemcpyDeviceToHost, stream));
-        DS_HIP(hipStreamSynchronize(stream));
+        DS_HIP(ds_memcpy_async(h_sums, d_red, sizeof(double) * (S_COUNT + 1), hipMemcpyDeviceToHost, stream));
+        DS_HIP(ds_stream_synchronize(stream));
         for (int i = 0; i <= S_COUNT; ++i) S[i] = h_sums[i];
     }
     elapsed_agreed = S[S_COUNT];
@@ -1490,7 +1508,7 @@ int Solver::norms_light(double *S) {
     DS_CHECK(flush_alpha());
     const KktCoef k = kkt_coef();
     FOR_SLABS(s) {
-        DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+        DS_HIP(ds_memset_async(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
         FusedArgs a{};
         a.q_old = s.q_old;
         a.q = s.q;
@@ -1681,26 +1699,26 @@ int Solver::step(bool *brk) {
     if (split) {
         // as below, and the q halo / u0 tail of the last q-step travel (main stream) while stream_z works on the
         // cone chunks that do not read the halo; only the last chunk of every slab waits for it
-        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_fork, s.st));
+        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_fork, s.st));
         DS_CHECK(ensure_halo());
         FOR_SLABS(s) {
-            DS_HIP(hipEventRecord(s.ev_halo, s.st));
-            DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
+            DS_HIP(ds_event_record(s.ev_halo, s.st));
+            DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
         }
         DS_CHECK(phase_z(true, 1));
-        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_halo, 0));
+        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st_z, s.ev_halo, 0));
         DS_CHECK(phase_z(true, 2));
-        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
+        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_join, s.st_z));
         DS_CHECK(phase_phi());
-        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
+        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.ev_join, 0));
     } else if (overlap) {
         // fork: cone pass on stream_z beside the phi step on the main stream, join before the q-step
         DS_CHECK(ensure_halo());
         DS_CHECK(fork_z());
         DS_CHECK(phase_z(true));
-        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
+        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_join, s.st_z));
         DS_CHECK(phase_phi());
-        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st, s.ev_join, 0));
+        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.ev_join, 0));
     } else {
         DS_CHECK(phase_phi());
         DS_CHECK(phase_z(false));
@@ -1710,16 +1728,16 @@ int Solver::step(bool *brk) {
     if (fold) {
         // every region of partial sums is cleared before the q-step writes region 0; kkt_sums() then only adds the cell,
         // border and (time slabs) first-layer launches
-        FOR_SLABS(s) DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+        FOR_SLABS(s) DS_HIP(ds_memset_async(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
     }
     if (split_q) {
         // the chunks of the q-step that need neither neighbour run on stream_z while the phi head and the adjoint
         // tails travel on the main stream; the first and the last chunk follow the exchange
-        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_fork, s.st));    // phi^{k+1} and the cone pass are complete
+        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_fork, s.st));    // phi^{k+1} and the cone pass are complete
         DS_CHECK(phase_z_tails());                               // enqueued first: the exchange gets its CUs at once
-        FOR_SLABS(s) DS_HIP(hipStreamWaitEvent(s.st_z, s.ev_fork, 0));
+        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
         DS_CHECK(phase_q(1, fold));
-        FOR_SLABS(s) DS_HIP(hipEventRecord(s.ev_join, s.st_z));
+        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_join, s.st_z));
         DS_CHECK(phase_q(2, fold));
     } else {
         DS_CHECK(phase_z_tails());
@@ -1737,6 +1755,14 @@ int Solver::run(i64 n_iters, i64 *done) {
     if (!begun || finished) { set_error("run() needs begin() and must precede finish()"); return DOTSOCP_ESTATE; }
     cur_dev = -1;
     DS_CHECK(use_dev(device));
+    // while the loop runs, whatever enqueues work on a slab's streams is issued by that slab's own host thread (defer.h)
+    struct DeferScope {
+        DeferCtx *ctx;
+        int err = 0;
+        explicit DeferScope(DeferCtx *c) : ctx(c) { if (ctx) { g_defer = ctx; ctx->begin(); } }
+        int close() { if (ctx) { err = ctx->end(); g_defer = nullptr; ctx = nullptr; } return err; }
+        ~DeferScope() { (void)close(); }
+    } scope(defer.get());
     i64 n = 0;
     while (it < opts.maxit && !stopped) {
         if (n_iters >= 0 && n >= n_iters) break;
@@ -1748,6 +1774,10 @@ int Solver::run(i64 n_iters, i64 *done) {
     DS_CHECK(ensure_halo());          // callers between run() calls see exchanged halos
     DS_CHECK(sync_all());
     DS_CHECK(prof_flush());
+    if (const int derr = scope.close()) {
+        set_error("a HIP call issued by a slab thread failed: %s", hipGetErrorString((hipError_t)derr));
+        return DOTSOCP_EHIP;
+    }
     if (done) *done = n;
     return 0;
 }

@@ -53,7 +53,7 @@ int Solver::acc_set_anchors() {
     FOR_SLABS(s) {
         const Grid &g = s.g;
         auto cp = [&](double *dst, const double *src, i64 n) {
-            return hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s.st);
+            return ds_memcpy_async(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s.st);
         };
         DS_HIP(cp(s.phi_a, s.phi, g.NphiAlloc));
         DS_HIP(cp(s.q_a, s.q, g.NqAlloc));

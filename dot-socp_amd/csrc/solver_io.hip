@@ -74,8 +74,8 @@ int Solver::jump_from(Solver &coarse) {
     auto pull = [&](Slab &f, double *dst, const Slab &c, const double *src, i64 count) -> int {
         if (count <= 0) return 0;
         const size_t bytes = sizeof(double) * (size_t)count;
-        if (f.dev == c.dev) DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, f.st));
-        else DS_HIP(hipMemcpyPeerAsync(dst, f.dev, src, c.dev, bytes, f.st));
+        if (f.dev == c.dev) DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, f.st));
+        else DS_HIP(ds_memcpy_peer_async(dst, f.dev, src, c.dev, bytes, f.st));
         return 0;
     };
     const bool direct = !multi() && !coarse.multi() && slabs[0].dev == coarse.slabs[0].dev;
@@ -143,7 +143,7 @@ int Solver::jump_from(Solver &coarse) {
     FOR_SLABS(f) {
         DS_CHECK(launch_grad(f.g, lc, f.phi, f.q, f.st));
         DS_CHECK(scale_owned(f, f.q, 1.0, false));
-        DS_HIP(hipMemsetAsync(f.z, 0, sizeof(double) * 10 * f.g.Nz, f.st));       // var.z of initialize.m
+        DS_HIP(ds_memset_async(f.z, 0, sizeof(double) * 10 * f.g.Nz, f.st));       // var.z of initialize.m
     }
     DS_CHECK(sync_all());
     return 0;

@@ -122,7 +122,7 @@ int Solver::palm_step(bool *brk) {
     if (fold) {
         const KktCoef k = kkt_coef();
         FOR_SLABS(s) {
-            DS_HIP(hipMemsetAsync(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+            DS_HIP(ds_memset_async(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
             QStepExtra ex{};
             ex.apend = 0; ex.amul = 1.0; ex.adiv = 1.0;
             ex.partials = kkt_qstep_partials(s.g, s.kw);

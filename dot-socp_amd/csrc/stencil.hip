@@ -32,9 +32,9 @@ int launch_rhs(const Grid &g, const LoopCoef &c, const double *q, const double *
     if (g.Nphi <= 0) return 0;
     RhsArgs a{g, c.at, c.ax, c.ay, q, alpha, cvec, weight, u0_prev};
     if (weight)
-        hipLaunchKernelGGL(k_rhs<true>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, a, rhs);
+        DS_KLAUNCH(k_rhs<true>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, a, rhs);
     else
-        hipLaunchKernelGGL(k_rhs<false>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, a, rhs);
+        DS_KLAUNCH(k_rhs<false>, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, a, rhs);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -55,9 +55,9 @@ int launch_u0_tail(const Grid &g, const double *q, const double *alpha, const do
                    hipStream_t st) {
     if (g.ncl <= 0) return 0;
     if (weight)
-        hipLaunchKernelGGL(k_u0_tail<true>, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, q, alpha, weight, out);
+        DS_KLAUNCH(k_u0_tail<true>, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, q, alpha, weight, out);
     else
-        hipLaunchKernelGGL(k_u0_tail<false>, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, q, alpha, weight, out);
+        DS_KLAUNCH(k_u0_tail<false>, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, q, alpha, weight, out);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -147,13 +147,13 @@ static int launch_qstep_t(const Grid &g, const LoopCoef &c, const double *phi, c
                           double *alpha, hipStream_t st) {
     dim3 blk(TILE_Y, TILE_X);
     if (g.Nz > 0)
-        hipLaunchKernelGGL((k_qstep<WEIGHTED, 0>), tile_grid(g, g.ncl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
+        DS_KLAUNCH((k_qstep<WEIGHTED, 0>), tile_grid(g, g.ncl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
                            tail_by, q, alpha);
     if (g.bxLayer > 0)
-        hipLaunchKernelGGL((k_qstep<WEIGHTED, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
+        DS_KLAUNCH((k_qstep<WEIGHTED, 1>), tile_grid(g, g.ntl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
                            tail_by, q, alpha);
     if (g.byLayer > 0)
-        hipLaunchKernelGGL((k_qstep<WEIGHTED, 2>), tile_grid(g, g.ntl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
+        DS_KLAUNCH((k_qstep<WEIGHTED, 2>), tile_grid(g, g.ntl), blk, 0, st, g, c, phi, z, beta, weight, tail_bx,
                            tail_by, q, alpha);
     DS_HIP(hipGetLastError());
     return 0;
@@ -251,7 +251,7 @@ static int launch_qstep_fused_t(const Grid &g, const LoopCoef &c, const FusedGeo
                                 const double *tail_bx, const double *tail_by, double *q, double *alpha,
                                 hipStream_t st) {
     dim3 blk(TILE_Y, TILE_X);
-    hipLaunchKernelGGL((k_qstep_fused<WEIGHTED, 3>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
+    DS_KLAUNCH((k_qstep_fused<WEIGHTED, 3>), tile_grid(g, g.ntl), blk, 0, st, g, c, fg, phi, q2, sx, sy, weight,
                        tail_bx, tail_by, q, alpha, (const double *)nullptr);
     DS_HIP(hipGetLastError());
     return 0;
@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(256) k_rhs_sigma_fix(double *__restrict__ rhs,
 
 int launch_rhs_sigma_fix(double *rhs, const double *r, double *cvec, i64 n, double factor, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_rhs_sigma_fix, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, rhs, r, cvec, n, factor);
+    DS_KLAUNCH(k_rhs_sigma_fix, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, rhs, r, cvec, n, factor);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -820,15 +820,15 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     if (var == 0 && !a.partials && qtx == 2 * TILE_X) {
         dim3 grid2((unsigned)fg.nyblk, (unsigned)((g.nx + 2 * TILE_X - 1) / (2 * TILE_X)), (unsigned)zcount);
         dim3 blk2(TILE_Y, 2 * TILE_X);
-        if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, false, 2 * TILE_X>), grid2, blk2, 0, st, g, c, fg, a);
-        else hipLaunchKernelGGL((k_qstep_rhs<false, 0, false, 2 * TILE_X>), grid2, blk2, 0, st, g, c, fg, a);
+        if (a.weight) DS_KLAUNCH((k_qstep_rhs<true, 0, false, 2 * TILE_X>), grid2, blk2, 0, st, g, c, fg, a);
+        else DS_KLAUNCH((k_qstep_rhs<false, 0, false, 2 * TILE_X>), grid2, blk2, 0, st, g, c, fg, a);
         DS_HIP(hipGetLastError());
         return 0;
     }
-#define QRHS_LAUNCH(W, V) hipLaunchKernelGGL((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
+#define QRHS_LAUNCH(W, V) DS_KLAUNCH((k_qstep_rhs<W, V>), grid, blk, 0, st, g, c, fg, a)
     if (var == 0 && a.partials) {          // iteration with a KKT check
-        if (a.weight) hipLaunchKernelGGL((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
-        else hipLaunchKernelGGL((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
+        if (a.weight) DS_KLAUNCH((k_qstep_rhs<true, 0, true>), grid, blk, 0, st, g, c, fg, a);
+        else DS_KLAUNCH((k_qstep_rhs<false, 0, true>), grid, blk, 0, st, g, c, fg, a);
     } else if (a.weight) {
         if (var == 0) QRHS_LAUNCH(true, 0); else if (var == 1) QRHS_LAUNCH(true, 1); else QRHS_LAUNCH(true, 2);
     } else {
@@ -851,7 +851,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_rhs_fixup(Grid g, double at,
 }
 
 int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, double *rhs, hipStream_t st) {
-    hipLaunchKernelGGL(k_rhs_fixup, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c.at, u0_prev, rhs);
+    DS_KLAUNCH(k_rhs_fixup, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c.at, u0_prev, rhs);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_grad(Grid g, LoopCoef c, con
 }
 
 int launch_grad(const Grid &g, const LoopCoef &c, const double *phi, double *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_grad, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, phi, out);
+    DS_KLAUNCH(k_grad, tile_grid(g, g.ntl), dim3(TILE_Y, TILE_X), 0, st, g, c, phi, out);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_tail_finalize(Grid g, LoopCo
 
 int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,
                          const double *sy, double *tail_bx, double *tail_by, hipStream_t st) {
-    hipLaunchKernelGGL(k_tail_finalize, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c, fg, q2, sx, sy, tail_bx,
+    DS_KLAUNCH(k_tail_finalize, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, c, fg, q2, sx, sy, tail_bx,
                        tail_by);
     DS_HIP(hipGetLastError());
     return 0;
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_tail(Grid g, const doubl
 
 int launch_kkt_tail(const Grid &g, const double *alpha, const double *beta, const double *weight, double *a0,
                     double *a0w, double *bt_bx, double *bt_by, hipStream_t st) {
-    hipLaunchKernelGGL(k_kkt_tail, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, alpha, beta, weight, a0, a0w, bt_bx,
+    DS_KLAUNCH(k_kkt_tail, tile_grid(g, 1), dim3(TILE_Y, TILE_X), 0, st, g, alpha, beta, weight, a0, a0w, bt_bx,
                        bt_by);
     DS_HIP(hipGetLastError());
     return 0;
@@ -988,8 +988,8 @@ __global__ void __launch_bounds__(256) k_pencil_pack(PencilCuts pc, i64 plane, i
 int launch_pencil_pack(bool pack, const PencilCuts &pc, i64 plane, i64 ntl, double *slab, double *stage, hipStream_t st) {
     if (plane * ntl <= 0) return 0;
     dim3 grid((unsigned)((plane + 255) / 256), (unsigned)ntl);
-    if (pack) hipLaunchKernelGGL(k_pencil_pack<true>, grid, dim3(256), 0, st, pc, plane, ntl, slab, stage);
-    else hipLaunchKernelGGL(k_pencil_pack<false>, grid, dim3(256), 0, st, pc, plane, ntl, slab, stage);
+    if (pack) DS_KLAUNCH(k_pencil_pack<true>, grid, dim3(256), 0, st, pc, plane, ntl, slab, stage);
+    else DS_KLAUNCH(k_pencil_pack<false>, grid, dim3(256), 0, st, pc, plane, ntl, slab, stage);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, i64 n, do
 
 int launch_scale(double *x, i64 n, double mul, double div, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_scale, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, n, mul, div,
+    DS_KLAUNCH(k_scale, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, n, mul, div,
                        (int)(mul != 1.0));
     DS_HIP(hipGetLastError());
     return 0;

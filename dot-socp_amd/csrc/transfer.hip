@@ -83,7 +83,7 @@ int launch_prolong_phi(const Grid &gf, const Grid &gc, const double *phic, doubl
                        hipStream_t st, i64 tc0) {
     if (gf.ntl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ntl);
-    hipLaunchKernelGGL(k_prolong_phi, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx, phic, phif,
+    DS_KLAUNCH(k_prolong_phi, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx, phic, phif,
                        sc_in, sc_out);
     DS_HIP(hipGetLastError());
     return 0;
@@ -93,7 +93,7 @@ int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, dou
                         double sc_in1, double sc_out, hipStream_t st, i64 tc0, i64 Nzc) {
     if (gf.ncl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ncl);
-    hipLaunchKernelGGL(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx,
+    DS_KLAUNCH(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx,
                        Nzc < 0 ? gc.Nz : Nzc, gf.Nz, betac, betaf, neg, sc_in0, sc_in1, sc_out);
     DS_HIP(hipGetLastError());
     return 0;
@@ -105,14 +105,14 @@ __global__ void __launch_bounds__(256) k_fill(double *__restrict__ x, i64 n, dou
 
 int launch_fill(double *x, i64 n, double v, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_fill, dim3(launch_blocks(n, 256, 1 << 16)), dim3(256), 0, st, x, n, v);
+    DS_KLAUNCH(k_fill, dim3(launch_blocks(n, 256, 1 << 16)), dim3(256), 0, st, x, n, v);
     DS_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_scale_div(double *x, const double *w, i64 n, double sc, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_scale_div, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, w, n, sc);
+    DS_KLAUNCH(k_scale_div, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, w, n, sc);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_out_tail(Grid g, OutArgs a, double *__r
 int launch_out_tail(const Grid &g, const double *alpha, const double *weight, double sig, double cD, double *out,
                     hipStream_t st) {
     OutArgs a{nullptr, alpha, weight, nullptr, nullptr, nullptr, sig, cD, 0.0};
-    hipLaunchKernelGGL(k_out_tail, dim3((unsigned)((g.plane + 255) / 256)), dim3(256), 0, st, g, a, out);
+    DS_KLAUNCH(k_out_tail, dim3((unsigned)((g.plane + 255) / 256)), dim3(256), 0, st, g, a, out);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -208,7 +208,7 @@ int launch_outputs(const Grid &g, const double *q, const double *alpha, const do
     const i64 layers = (which >= 3) ? g.ncl : g.ntl;
     if (layers <= 0) return 0;
     dim3 grid((unsigned)((g.ny + TILE_Y - 1) / TILE_Y), (unsigned)((g.nx + TILE_X - 1) / TILE_X), (unsigned)layers);
-    hipLaunchKernelGGL(k_outputs, grid, dim3(TILE_Y, TILE_X), 0, st, g, a, which, out);
+    DS_KLAUNCH(k_outputs, grid, dim3(TILE_Y, TILE_X), 0, st, g, a, which, out);
     DS_HIP(hipGetLastError());
     return 0;
 }

@@ -329,10 +329,10 @@ int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, con
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
     const dim3 grid((unsigned)((g.plane + 255) / 256));
     const int rw = tri_reg_width(g.ntl);
-    if (rw == 16) hipLaunchKernelGGL(k_tri_local_reg<16>, grid, dim3(256), 0, st, t, r, send);
-    else if (rw == 32) hipLaunchKernelGGL(k_tri_local_reg<32>, grid, dim3(256), 0, st, t, r, send);
-    else if (rw == 64) hipLaunchKernelGGL(k_tri_local_reg<64>, grid, dim3(256), 0, st, t, r, send);
-    else hipLaunchKernelGGL(k_tri_local, grid, dim3(256), 0, st, t, r, send);
+    if (rw == 16) DS_KLAUNCH(k_tri_local_reg<16>, grid, dim3(256), 0, st, t, r, send);
+    else if (rw == 32) DS_KLAUNCH(k_tri_local_reg<32>, grid, dim3(256), 0, st, t, r, send);
+    else if (rw == 64) DS_KLAUNCH(k_tri_local_reg<64>, grid, dim3(256), 0, st, t, r, send);
+    else DS_KLAUNCH(k_tri_local, grid, dim3(256), 0, st, t, r, send);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -346,10 +346,10 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
     q.P = pc.world; q.rank = rank; q.l0 = l0; q.nl = nl; q.nt = nt;
     for (int p = 0; p < pc.world; ++p) q.slab_n[p] = slab_n[p];
     const dim3 grid((unsigned)((nl + 127) / 128));
-    if (pc.world <= 4) hipLaunchKernelGGL(k_tri_reduced<4>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
-    else if (pc.world <= 8) hipLaunchKernelGGL(k_tri_reduced<8>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
-    else if (pc.world <= 16) hipLaunchKernelGGL(k_tri_reduced<16>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
-    else hipLaunchKernelGGL(k_tri_reduced<DS_MAX_WORLD>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    if (pc.world <= 4) DS_KLAUNCH(k_tri_reduced<4>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    else if (pc.world <= 8) DS_KLAUNCH(k_tri_reduced<8>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    else if (pc.world <= 16) DS_KLAUNCH(k_tri_reduced<16>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
+    else DS_KLAUNCH(k_tri_reduced<DS_MAX_WORLD>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -359,10 +359,10 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
     const dim3 grid((unsigned)((g.plane + 255) / 256));
     const int rw = tri_reg_width(g.ntl);
-    if (rw == 16) hipLaunchKernelGGL(k_tri_final_reg<16>, grid, dim3(256), 0, st, t, back, x);
-    else if (rw == 32) hipLaunchKernelGGL(k_tri_final_reg<32>, grid, dim3(256), 0, st, t, back, x);
-    else if (rw == 64) hipLaunchKernelGGL(k_tri_final_reg<64>, grid, dim3(256), 0, st, t, back, x);
-    else hipLaunchKernelGGL(k_tri_final, grid, dim3(256), 0, st, t, back, x, qinv);
+    if (rw == 16) DS_KLAUNCH(k_tri_final_reg<16>, grid, dim3(256), 0, st, t, back, x);
+    else if (rw == 32) DS_KLAUNCH(k_tri_final_reg<32>, grid, dim3(256), 0, st, t, back, x);
+    else if (rw == 64) DS_KLAUNCH(k_tri_final_reg<64>, grid, dim3(256), 0, st, t, back, x);
+    else DS_KLAUNCH(k_tri_final, grid, dim3(256), 0, st, t, back, x, qinv);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -381,7 +381,7 @@ int launch_gather_msgs(const GatherMsgs &m, hipStream_t st) {
     for (int i = 0; i < m.n; ++i) cmax = m.count[i] > cmax ? m.count[i] : cmax;
     if (cmax <= 0) return 0;
     const unsigned bx = (unsigned)launch_blocks(cmax, 256, 256);
-    hipLaunchKernelGGL(k_gather_msgs, dim3(bx, (unsigned)m.n), dim3(256), 0, st, m);
+    DS_KLAUNCH(k_gather_msgs, dim3(bx, (unsigned)m.n), dim3(256), 0, st, m);
     DS_HIP(hipGetLastError());
     return 0;
 }

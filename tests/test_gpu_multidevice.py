@@ -209,3 +209,24 @@ def test_random_stream_stalls_change_nothing():
         assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
         hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][-1])
     assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
+def test_slab_threads_change_nothing():
+    """One host thread per slab issues that slab's launches, copies, event records and stream waits while run() is active
+    (csrc/defer.h; the default of this mode) -- against the same runs with everything issued by the caller's thread
+    (DOTSOCP_HOST_THREADS=0).  The device sees the same operations in the same per-stream order with the same event
+    dependencies, so iterates, KKT histories and outputs of all three loops are bit-identical -- also under random
+    stream stalls, which move the relative timing of the slab threads' work around, and with the pull launches
+    replaced by event-ordered copies (many more cross-slab events per iteration)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for threads, stress, batch in (("0", "0", "1"), ("1", "0", "1"), ("1", "1", "1"), ("1", "1", "0")):
+        env = dict(os.environ, DOTSOCP_HOST_THREADS=threads, DOTSOCP_STRESS_STREAMS=stress, DOTSOCP_MSG_BATCH=batch,
+                   DOTSOCP_TRI_GATHER=batch, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        out = subprocess.run([sys.executable, "-c", _STRESS_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+        hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][-1])
+    assert len(set(hashes)) == 1, hashes
