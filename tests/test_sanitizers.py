@@ -40,3 +40,19 @@ def test_cpu_side_c_is_clean_under_asan_and_ubsan():
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "0 failed" in run.stdout
     assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
+
+
+def test_slab_thread_layer_is_clean_under_tsan():
+    """ThreadSanitizer over the slab-thread layer (dot-socp_amd/csrc/defer.h, defer.hip: one issuing thread per time slab
+    in the single-process multi-slab modes): built with g++ against a stub of the few HIP declarations it uses and
+    driven by tests/san/defer_tsan.cpp with the call pattern of the time-slab loop -- per-stream order kept, every stream
+    wait bound to the record that preceded it in host order, no data race, no deadlock."""
+    os.makedirs(OUT, exist_ok=True)
+    csrc = os.path.join(ROOT, "dot-socp_amd", "csrc")
+    exe = os.path.join(OUT, "defer_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-x", "c++",
+                           "-I" + os.path.join(ROOT, "tests", "san", "hipstub"), "-I" + csrc,
+                           os.path.join(csrc, "defer.hip"), os.path.join(ROOT, "tests", "san", "defer_tsan.cpp"), "-o", exe])
+    run = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "0 failed" in run.stdout and "ThreadSanitizer" not in run.stderr
