@@ -50,13 +50,11 @@ struct PfaDims {
     static constexpr int N1 = N1_, N2 = N2_, N = N1_ * N2_, NH = (N1_ * N2_ - 1) / 2;
     static constexpr int I2 = pfa_modinv(N2_, N1_);     // N2^-1 mod N1
     static constexpr int I1 = pfa_modinv(N1_, N2_);     // N1^-1 mod N2
-    // position of element p inside the [N1][N2] image of a line, map A and map B (a transform that reads through one
-    // writes through the other)
-    __device__ __forceinline__ static int posA(int p) { return (p % N1) * N2 + (p % N2); }
-    __device__ __forceinline__ static int posB(int p) { return ((p * I2) % N1) * N2 + ((p * I1) % N2); }
+    // Position of element p inside the [N1][N2] image of a line: map A: (p mod N1) N2 + (p mod N2), map B:
+    // ((p I2) mod N1) N2 + ((p I1) mod N2) -- a transform that reads through one writes through the other.  The kernels
+    // look the positions up (PfaPlan::pos, built on the host together with Makhoul's reordering v[j] = x[2j],
+    // v[n-1-j] = x[2j+1], mirt_dctn.m:71).
 };
-
-__device__ __forceinline__ int pfa_makhoul(int k, int n) { return (k & 1) ? (n - 1 - (k >> 1)) : (k >> 1); }
 
 // In-place folded DFT of the M values p[0], p[ES], ..., p[(M-1) ES] (doubles; the own component of complex elements)
 // with the other component one double beside each of them.  part = 0: own = real part, 1: own = imaginary part.
@@ -184,9 +182,13 @@ struct PfaSolve {
 template <class PF, int P, int T, int MODE /*0 forward, 1 inverse, 2 t-axis solve*/, bool VEC>
 __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const double *__restrict__ src, double *__restrict__ dst, PfaGeom g,
                                                     PfaSolve sa, const double2 *__restrict__ ww,
-                                                    const double *__restrict__ t1, const double *__restrict__ t2) {
+                                                    const double *__restrict__ t1, const double *__restrict__ t2,
+                                                    const unsigned short *__restrict__ pos) {
     extern __shared__ double2 tile[];
     constexpr int N = PF::N, NH = PF::NH;
+    // position tables (PfaPlan::pos): the two index maps composed with Makhoul's reordering, looked up instead of
+    // recomputed (the modular arithmetic was a third of these kernels' vector instructions)
+    const unsigned short *tA = pos, *tB = pos + N, *tAk = pos + 2 * N, *tBm = pos + 3 * N;
     constexpr int KS = T / P;                      // element step of the load / store loops
     static_assert(T % P == 0, "threads per pair");
     const ctab_t tab1 = as_ctab(t1), tab2 = as_ctab(t2);
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int e = e0 + (b0 + u) * KS;
-                if (e < N) mine[PF::posA(pfa_makhoul(e, N))] = v[u];
+                if (e < N) mine[tA[e]] = v[u];
             }
         }
     } else {
@@ -259,8 +261,8 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
                 } else {
                     double2 gk, gm;
                     pfa_pre(Pfa4{vk[u].x, vk[u].y, vm[u].x, vm[u].y}, wk[u], wm[u], gk, gm);
-                    mine[PF::posA(k)] = gk;
-                    mine[PF::posA(N - k)] = gm;
+                    mine[tAk[k]] = gk;
+                    mine[tAk[N - k]] = gm;
                 }
             }
         }
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
                 continue;
             }
             const int m = N - k;
-            const int ik = PF::posB(k), im = PF::posB(m);
+            const int ik = tB[k], im = tB[m];
             const double2 wk = ww[k], wm = ww[m];
             Pfa4 x = pfa_post(mine[ik], mine[im], wk, wm);
             const double ctk = sa.ct[k], ctm = sa.ct[m];
@@ -293,8 +295,8 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
             if (lbk == 0.0) lbk = 1.0;
             if (lam == 0.0) lam = 1.0;
             if (lbm == 0.0) lbm = 1.0;
-            x.ak = x.ak / (sa.kscale * lak);
-            x.bk = x.bk / (sa.kscale * lbk);
+            x.ak = x.ak / (sa.kscale * lak);       // (a reciprocal seed + Newton steps instead of the four IEEE divisions:
+            x.bk = x.bk / (sa.kscale * lbk);       //  measured, no change in the pass's time -- not kept)
             x.am = x.am / (sa.kscale * lam);
             x.bm = x.bm / (sa.kscale * lbm);
             double2 gk, gm;
@@ -315,86 +317,91 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
                 continue;
             }
             const int m = N - k;
-            const Pfa4 x = pfa_post(mine[PF::posB(k)], mine[PF::posB(m)], ww[k], ww[m]);
+            const Pfa4 x = pfa_post(mine[tB[k]], mine[tB[m]], ww[k], ww[m]);
             st2((i64)k * g.del, x.ak, x.bk);
             st2((i64)m * g.del, x.am, x.bm);
         }
     } else {
         for (int e = e0; e < N; e += KS) {
-            const int p = pfa_makhoul(e, N);
-            const double2 v = mine[MODE == 1 ? PF::posB(p) : PF::posA(p)];
+            const double2 v = mine[MODE == 1 ? tBm[e] : tA[e]];
             st2((i64)e * g.del, v.x, v.y);
         }
     }
 }
 
-// Axis 0: lines contiguous in memory (line L starts at L * lineStride), a tile = 2 P consecutive lines.
+// Axis 0: lines contiguous in memory (line L starts at L * lineStride), a tile = 2 P consecutive lines.  The T threads
+// form P groups of GS = T / P; group r owns pair r (lines 2 r, 2 r + 1) and its lanes walk the line: consecutive lanes
+// touch consecutive elements (coalesced), no index is ever divided, and both lines of a pair travel together so that
+// the LDS image is written in whole 16-byte values.
 template <class PF, int P, int T, bool INV>
 __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_axis0(const double *__restrict__ src, double *__restrict__ dst, i64 nLines,
                                                   i64 sline, i64 dline, const double2 *__restrict__ ww,
-                                                  const double *__restrict__ t1, const double *__restrict__ t2) {
+                                                  const double *__restrict__ t1, const double *__restrict__ t2,
+                                                  const unsigned short *__restrict__ pos) {
     extern __shared__ double2 tile[];
     constexpr int N = PF::N, NH = PF::NH;
+    constexpr int GS = T / P;
+    static_assert(T % P == 0 && (GS & (GS - 1)) == 0, "threads per pair: a power of two");
+    const unsigned short *tA = pos, *tB = pos + N, *tAk = pos + 2 * N, *tBm = pos + 3 * N;
     const ctab_t tab1 = as_ctab(t1), tab2 = as_ctab(t2);
     const int tid = threadIdx.x;
-    const i64 L0 = (i64)blockIdx.x * (2 * P);
+    const int r = tid / GS, j = tid % GS;
+    const i64 La = (i64)blockIdx.x * (2 * P) + 2 * r;
+    const bool okA = La < nLines, okB = La + 1 < nLines;
+    const double *sa = src + (okA ? La : 0) * sline, *sb = src + (okB ? La + 1 : 0) * sline;
+    double *da = dst + La * dline, *db = da + dline;
+    double2 *mine = tile + r * N;
     // ---- load ----
     if (!INV) {
-        constexpr int TOTAL = 2 * P * N;
-        constexpr int NIT = (TOTAL + T - 1) / T;
-        constexpr int NB = NIT < 8 ? NIT : 8;
+        constexpr int NIT = (N + GS - 1) / GS;
+        constexpr int NB = NIT < 9 ? NIT : 9;
         for (int b0 = 0; b0 < NIT; b0 += NB) {
-            double v[NB];
+            double2 v[NB];
+            int p[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int idx = tid + (b0 + u) * T;
-                const int l = idx / N, e = idx - l * N;
-                v[u] = (idx < TOTAL && L0 + l < nLines) ? src[(L0 + l) * sline + e] : 0.0;
+                const int e = j + (b0 + u) * GS;
+                const int ec = e < N ? e : 0;
+                v[u] = make_double2(okA ? sa[ec] : 0.0, okB ? sb[ec] : 0.0);
+                p[u] = tA[ec];
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int idx = tid + (b0 + u) * T;
-                if (idx >= TOTAL) continue;
-                const int l = idx / N, e = idx - l * N;
-                ((double *)(tile + (l >> 1) * N + PF::posA(pfa_makhoul(e, N))))[l & 1] = v[u];
+                const int e = j + (b0 + u) * GS;
+                if (e < N && (b0 + u) < NIT) mine[p[u]] = v[u];
             }
         }
     } else {
-        constexpr int TOTAL = P * (NH + 1);
-        constexpr int NIT = (TOTAL + T - 1) / T;
-        constexpr int NB = NIT < 4 ? NIT : 4;
+        constexpr int NIT = (NH + 1 + GS - 1) / GS;
+        constexpr int NB = NIT < 5 ? NIT : 5;
         for (int b0 = 0; b0 < NIT; b0 += NB) {
             Pfa4 x[NB];
             double2 wk[NB], wm[NB];
+            int pk[NB], pm[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int idx = tid + (b0 + u) * T;
-                const int r = idx / (NH + 1), k = idx - r * (NH + 1);
-                const bool in = idx < TOTAL;
-                const int kc = in ? k : 0, mc = kc ? N - kc : 0;
-                const i64 La = L0 + 2 * r;
-                const bool okA = in && La < nLines, okB = in && La + 1 < nLines;
-                const double *a = src + La * sline, *b = a + sline;
-                x[u].ak = okA ? a[kc] : 0.0;
-                x[u].am = okA ? a[mc] : 0.0;
-                x[u].bk = okB ? b[kc] : 0.0;
-                x[u].bm = okB ? b[mc] : 0.0;
+                const int k = j + (b0 + u) * GS;
+                const int kc = k <= NH ? k : 0, mc = kc ? N - kc : 0;
+                x[u].ak = okA ? sa[kc] : 0.0;
+                x[u].am = okA ? sa[mc] : 0.0;
+                x[u].bk = okB ? sb[kc] : 0.0;
+                x[u].bm = okB ? sb[mc] : 0.0;
                 wk[u] = ww[kc];
                 wm[u] = ww[mc];
+                pk[u] = tAk[kc];
+                pm[u] = tAk[mc];
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int idx = tid + (b0 + u) * T;
-                if (idx >= TOTAL) continue;
-                const int r = idx / (NH + 1), k = idx - r * (NH + 1);
-                double2 *mine = tile + r * N;
+                const int k = j + (b0 + u) * GS;
+                if (k > NH || (b0 + u) >= NIT) continue;
                 if (k == 0) {
                     mine[0] = make_double2(wk[u].x * x[u].ak, wk[u].x * x[u].bk);
                 } else {
                     double2 gk, gm;
                     pfa_pre(x[u], wk[u], wm[u], gk, gm);
-                    mine[PF::posA(k)] = gk;
-                    mine[PF::posA(N - k)] = gm;
+                    mine[pk[u]] = gk;
+                    mine[pm[u]] = gm;
                 }
             }
         }
@@ -403,30 +410,24 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_axis0(const d
     pfa_tile_dft<PF, P, T>(tile, tid, tab1, tab2);
     // ---- store ----
     if (!INV) {
-        for (int idx = tid; idx < P * (NH + 1); idx += T) {
-            const int r = idx / (NH + 1), k = idx - r * (NH + 1);
-            const i64 La = L0 + 2 * r;
-            const bool okA = La < nLines, okB = La + 1 < nLines;
-            double *a = dst + La * dline, *b = a + dline;
-            const double2 *mine = tile + r * N;
+        for (int k = j; k <= NH; k += GS) {
             if (k == 0) {
                 const double w0 = ww[0].x;
                 const double2 v0 = mine[0];
-                if (okA) a[0] = w0 * v0.x;
-                if (okB) b[0] = w0 * v0.y;
+                if (okA) da[0] = w0 * v0.x;
+                if (okB) db[0] = w0 * v0.y;
                 continue;
             }
             const int m = N - k;
-            const Pfa4 x = pfa_post(mine[PF::posB(k)], mine[PF::posB(m)], ww[k], ww[m]);
-            if (okA) { a[k] = x.ak; a[m] = x.am; }
-            if (okB) { b[k] = x.bk; b[m] = x.bm; }
+            const Pfa4 x = pfa_post(mine[tB[k]], mine[tB[m]], ww[k], ww[m]);
+            if (okA) { da[k] = x.ak; da[m] = x.am; }
+            if (okB) { db[k] = x.bk; db[m] = x.bm; }
         }
     } else {
-        for (int idx = tid; idx < 2 * P * N; idx += T) {
-            const int l = idx / N, e = idx - l * N;
-            if (L0 + l >= nLines) continue;
-            const double2 v = tile[(l >> 1) * N + PF::posB(pfa_makhoul(e, N))];
-            dst[(L0 + l) * dline + e] = (l & 1) ? v.y : v.x;
+        for (int e = j; e < N; e += GS) {
+            const double2 v = mine[tBm[e]];
+            if (okA) da[e] = v.x;
+            if (okB) db[e] = v.y;
         }
     }
 }
@@ -438,6 +439,7 @@ struct PfaPlan {
     int n, n1, n2;
     double2 *ww;          // [n]  2 exp(-i pi k / 2n) / sqrt(2n), ww[0] /= sqrt(2)   (mirt_dctn.m:69-70)
     double *tab1, *tab2;  // folded cos / sin matrices of the N1- and N2-point DFTs
+    unsigned short *pos;  // [4][n] positions inside the [N1][N2] image: A(makhoul(e)), B(k), A(k), B(makhoul(e))
 };
 
 static bool pfa_factors(i64 n, int &n1, int &n2) {
@@ -484,7 +486,7 @@ PfaPlan *pfa_plan_create(i64 n) {
     if (!pfa_factors(n, n1, n2)) return nullptr;
     PfaPlan *p = new PfaPlan();
     p->n = (int)n; p->n1 = n1; p->n2 = n2;
-    p->ww = nullptr; p->tab1 = p->tab2 = nullptr;
+    p->ww = nullptr; p->tab1 = p->tab2 = nullptr; p->pos = nullptr;
     const long double PI = 3.141592653589793238462643383279502884L;
     std::vector<double2> ww((size_t)n);
     for (i64 k = 0; k < n; ++k) {
@@ -493,8 +495,25 @@ PfaPlan *pfa_plan_create(i64 n) {
         if (k == 0) sc /= sqrtl(2.0L);
         ww[k] = make_double2((double)(sc * cosl(a)), (double)(sc * sinl(a)));
     }
+    // the index maps of pfa.hip's header: A: p -> (p mod N1, p mod N2), B: p -> (p N2^-1 mod N1, p N1^-1 mod N2)
+    std::vector<unsigned short> pos((size_t)4 * n);
+    {
+        auto inv = [](int a, int m) { a %= (m > 0 ? m : 1); for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x; return 0; };
+        const int i2 = inv(n2, n1), i1 = inv(n1, n2);
+        auto A = [&](int q) { return (q % n1) * n2 + (q % n2); };
+        auto B = [&](int q) { return ((q * i2) % n1) * n2 + ((q * i1) % n2); };
+        auto mk = [&](int k) { return (k & 1) ? ((int)n - 1 - (k >> 1)) : (k >> 1); };
+        for (int e = 0; e < (int)n; ++e) {
+            pos[e] = (unsigned short)A(mk(e));
+            pos[(size_t)n + e] = (unsigned short)B(e);
+            pos[(size_t)2 * n + e] = (unsigned short)A(e);
+            pos[(size_t)3 * n + e] = (unsigned short)B(mk(e));
+        }
+    }
     if (hipMalloc(&p->ww, sizeof(double2) * n) != hipSuccess ||
         hipMemcpy(p->ww, ww.data(), sizeof(double2) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&p->pos, sizeof(unsigned short) * pos.size()) != hipSuccess ||
+        hipMemcpy(p->pos, pos.data(), sizeof(unsigned short) * pos.size(), hipMemcpyHostToDevice) != hipSuccess ||
         pfa_make_tab(&p->tab1, n1) != 0 || pfa_make_tab(&p->tab2, n2) != 0) {
         pfa_plan_destroy(p);
         return nullptr;
@@ -507,6 +526,7 @@ void pfa_plan_destroy(PfaPlan *p) {
     if (p->ww) (void)hipFree(p->ww);
     if (p->tab1) (void)hipFree(p->tab1);
     if (p->tab2) (void)hipFree(p->tab2);
+    if (p->pos) (void)hipFree(p->pos);
     delete p;
 }
 
@@ -567,7 +587,7 @@ static void pfa_launch_strided_n(const PfaPlan *p, const double *src, double *ds
     typedef typename S::D D;
     constexpr int P = S::P, T = S::T;
     const size_t lds = (size_t)P * N * sizeof(double2);
-#define PFA_GO(M, V) DS_KLAUNCH((k_pfa_strided<D, P, T, M, V>), dim3(blocks), dim3(T), lds, st, src, dst, g, sa, p->ww, p->tab1, p->tab2)
+#define PFA_GO(M, V) DS_KLAUNCH((k_pfa_strided<D, P, T, M, V>), dim3(blocks), dim3(T), lds, st, src, dst, g, sa, p->ww, p->tab1, p->tab2, p->pos)
     if (mode == 0) { if (vec) PFA_GO(0, true); else PFA_GO(0, false); }
     else if (mode == 1) { if (vec) PFA_GO(1, true); else PFA_GO(1, false); }
     else { if (vec) PFA_GO(2, true); else PFA_GO(2, false); }
@@ -580,9 +600,9 @@ static void pfa_launch_axis0_pt(const PfaPlan *p, const double *src, double *dst
     const size_t lds = (size_t)P * D::N * sizeof(double2);
     const unsigned blocks = (unsigned)((nLines + 2 * P - 1) / (2 * P));
     if (inverse)
-        DS_KLAUNCH((k_pfa_axis0<D, P, T, true>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
+        DS_KLAUNCH((k_pfa_axis0<D, P, T, true>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2, p->pos);
     else
-        DS_KLAUNCH((k_pfa_axis0<D, P, T, false>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2);
+        DS_KLAUNCH((k_pfa_axis0<D, P, T, false>), dim3(blocks), dim3(T), lds, st, src, dst, nLines, sline, dline, p->ww, p->tab1, p->tab2, p->pos);
 }
 
 template <int N>
