@@ -651,6 +651,8 @@ int pfa_launch_strided(const PfaPlan *p, const double *src, double *dst, i64 nyL
                        ((nrows == 1 || (srow > nyLines && drow > nyLines)) && sel > nyLines && del > nyLines);
     const bool vec = roomy && (srow % 2 == 0) && (sel % 2 == 0) && (drow % 2 == 0) && (del % 2 == 0) &&
                      (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    // (the fused t pass of length 129: 32 pairs x 512 threads and 8 pairs x 128 threads measured against the 16 x 256 of
+    // PfaShape<129>: Poisson solve 3.14 / 3.10 vs 3.04 ms at 1025 x 1025 x 129 -- not better)
     switch (p->n) {
 #define X(NV) case NV: pfa_launch_strided_n<NV>(p, src, dst, g, sa, mode, vec, (unsigned)tiles, st); break;
         PFA_FOR_LENGTHS(X)
