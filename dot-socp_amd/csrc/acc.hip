@@ -12,6 +12,9 @@
 //                store z_new, beta_new (other buffers: chunks re-read the cell in front of them) and
 //                emit q2 = F* B* (z_new + beta_new), the adjoint sums of the NEXT iteration's q-step (:229)
 //   MODE_GATHER: q2 = F* B* (z + beta) only.
+//   MODE_RESTART: MODE_FUSED for the iteration whose KKT check changed sigma (:346-358): beta and beta^+ are divided by the
+//                factor on the way (k_scale's arithmetic), the anchors are x^+ itself and are STORED here instead of read --
+//                one pass in place of two scalings, two anchor copies, two extrapolation passes and the gather pass.
 // traffic, MODE_FUSED: z, beta, z0, beta0 in + z, beta out + q + q2 = 8 (60 Nz + 2 Nq) bytes.
 // Mapping and gather: identical to the fused inPALM kernel (fused.hip / gather_tile.h).
 #include "device_utils.h"
@@ -20,7 +23,7 @@
 
 namespace dotsocp {
 
-enum { ACC_RAW = 0, ACC_FUSED = 1, ACC_GATHER = 2 };
+enum { ACC_RAW = 0, ACC_FUSED = 1, ACC_GATHER = 2, ACC_RESTART = 3 };
 
 template <int MODE, int XB>
 __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArgs a) {
@@ -79,14 +82,21 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                     double zn[10], bn[10];
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
-                        const double z0 = a.z0[j * g.Nz + i];
+                        const double z0 = (MODE == ACC_RESTART) ? v[j] : a.z0[j * g.Nz + i];
                         double t = a.om_rho * zz[j];
                         t = t + a.rho * v[j];
                         zn[j] = a.c1 * z0 + a.c2 * t;
                     }
+                    if (MODE == ACC_RESTART) {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) {
+                            b[j] = b[j] / a.bdiv;
+                            bp[j] = bp[j] / a.bdiv;
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
-                        const double b0 = a.beta0[j * g.Nz + i];
+                        const double b0 = (MODE == ACC_RESTART) ? bp[j] : a.beta0[j * g.Nz + i];
                         double t = a.om_rho * b[j];
                         t = t + a.rho * bp[j];
                         bn[j] = a.c1 * b0 + a.c2 * t;
@@ -96,6 +106,12 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                         for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zn[j];
 #pragma unroll
                         for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = bn[j];
+                        if (MODE == ACC_RESTART) {
+#pragma unroll
+                            for (int j = 0; j < 10; ++j) a.z0_out[j * g.Nz + i] = v[j];
+#pragma unroll
+                            for (int j = 0; j < 10; ++j) a.beta0_out[j * g.Nz + i] = bp[j];
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 10; ++j) w[j] = zn[j] + bn[j];
@@ -121,6 +137,7 @@ int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom 
         case ACC_RAW: DS_KLAUNCH((k_acc_cone<ACC_RAW, 4>), grid, blk, 0, st, g, c, a); break;
         case ACC_FUSED: DS_KLAUNCH((k_acc_cone<ACC_FUSED, 4>), grid, blk, 0, st, g, c, a); break;
         case ACC_GATHER: DS_KLAUNCH((k_acc_cone<ACC_GATHER, 4>), grid, blk, 0, st, g, c, a); break;
+        case ACC_RESTART: DS_KLAUNCH((k_acc_cone<ACC_RESTART, 4>), grid, blk, 0, st, g, c, a); break;
         default: set_error("bad acc cone mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());

@@ -90,6 +90,8 @@ struct AccArgs {
     const double *q;                 // q^+ of this iteration (modes 0, 1)
     const double *z_in, *beta_in;    // current state
     const double *z0, *beta0;        // Halpern anchors (mode 1)
+    double *z0_out, *beta0_out;      // mode 3: the anchors, written
+    double bdiv;                     // mode 3: factor of the sigma update
     double *z_out, *beta_out;        // mode 0: z^+, beta^+; mode 1: new state (buffers other than the inputs)
     double *q2, *sx, *sy;            // modes 1, 2: adjoint sums for the next q-step
     i64 TC;
@@ -99,7 +101,8 @@ struct AccCoef {
     double c1, c2, om_rho, rho;      // as above (Halpern) or c1 = theta/(2(k+theta)), c2 = k/(k+theta)
     double om_c1, c1c2;              // 1 - c1, c1 + c2 (theta != 2)
 };
-// mode 0: multiplier + z-step, raw outputs; 1: + Halpern step + gather; 2: gather of (z + beta) only
+// mode 0: multiplier + z-step, raw outputs; 1: + Halpern step + gather; 2: gather of (z + beta) only;
+// 3: mode 1 after a sigma update (beta, beta^+ divided by a.bdiv, anchors = x^+ stored)
 int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, AccArgs a, hipStream_t st);
 // element-wise extrapolation of one state array (modes: see acc.hip)
 int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,

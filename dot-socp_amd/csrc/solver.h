@@ -278,6 +278,10 @@ struct Solver {
     bool acc_halpern = true;
     bool acc_gather_valid = false;     // q2 / sx / sy hold F*B*(z + beta) of the current state
     bool acc_swapped = false;          // state and x^+ pointers are exchanged (during the KKT block / after a stop)
+    bool acc_post = true;              // Halpern: after a KKT check z and beta take ONE pass (k_acc_cone modes 1 / 3) instead of
+                                       // scalings, anchor copies, extrapolation passes and the gather pass (DOTSOCP_ACC_POST=0: off)
+    bool acc_light = false;            // inside that iteration's KKT block: the sigma update leaves z, beta and their anchors alone
+    double acc_factor = 1.0;           // factor of that block's sigma update (1: none)
     int acc_alloc();
     int acc_begin(const dotsocp_acc_opts *acc);
     int acc_step(bool *brk);

@@ -58,6 +58,7 @@ int Solver::acc_set_anchors() {
         DS_HIP(cp(s.phi_a, s.phi, g.NphiAlloc));
         DS_HIP(cp(s.q_a, s.q, g.NqAlloc));
         DS_HIP(cp(s.alpha_a, s.alpha, g.NqAlloc));
+        if (acc_light) continue;                 // z, beta: k_acc_cone<ACC_RESTART> stores their anchors
         DS_HIP(cp(s.z_a, s.z, 10 * g.Nz));
         DS_HIP(cp(s.beta_a, s.beta, 10 * g.Nz));
     }
@@ -72,6 +73,7 @@ int Solver::acc_begin(const dotsocp_acc_opts *acc) {
     acc_k = 0;                                                          // :158
     acc_gather_valid = false;
     acc_swapped = false;
+    if (const char *e = getenv("DOTSOCP_ACC_POST")) acc_post = (atoi(e) != 0);
     if (acc_halpern) DS_CHECK(acc_set_anchors());                       // :161-163 (after alpha, beta, c /= sigma)
     return 0;
 }
@@ -93,8 +95,9 @@ void Solver::acc_swap_state() {
 int Solver::acc_on_sigma_factor(double factor) {
     FOR_SLABS(s) {
         DS_CHECK(launch_scale(s.alpha_p, s.g.NqAlloc, 1.0, factor, s.st));
-        DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, s.st));
+        if (!acc_light) DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, s.st));
     }
+    acc_factor = factor;
     acc_k = 0;
     if (acc_halpern) DS_CHECK(acc_set_anchors());
     return 0;
@@ -176,6 +179,9 @@ int Solver::acc_step(bool *brk) {
     const bool kkt_due = opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit || timed_out;
     const AccCoef kc = acc_coef();
     const bool fold = acc_halpern && !kkt_due;      // extrapolation of z, beta inside the cone pass
+    // an iteration with a KKT check: x^+ is stored for the block; afterwards z and beta are extrapolated by a second cone pass
+    // that recomputes x^+ from the (untouched) state, applies the block's sigma factor and emits the next gather
+    const bool post = acc_halpern && kkt_due && acc_post;
 
     // ---- step q (:227-232) ----
     if (!acc_gather_valid) {
@@ -250,7 +256,11 @@ int Solver::acc_step(bool *brk) {
             prof_end(PH_COMM);
         }
         acc_swap_state();
-        DS_CHECK(kkt_block(adjustSigmaYes, timed_out, brk));
+        acc_light = post;
+        acc_factor = 1.0;
+        rc = kkt_block(adjustSigmaYes, timed_out, brk);
+        acc_light = false;
+        DS_CHECK(rc);
         if (*brk) return 0;                                // :322-325: the outputs are x^+ (pointers stay swapped)
         acc_swap_state();
     }
@@ -267,7 +277,19 @@ int Solver::acc_step(bool *brk) {
             DS_CHECK(launch_acc_interp(s.q, s.q_old, s.q_a, g.NqAlloc, k2, mode, write_aux, s.st));
             DS_CHECK(launch_acc_interp(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, mode, write_aux, s.st));
         }
-        if (fold) {
+        if (post) {
+            AccArgs a{};
+            a.q = s.q_old;                                 // raw q^+ (the sigma update does not touch q)
+            a.z_in = s.z; a.beta_in = s.beta;
+            a.z_out = s.z_p; a.beta_out = s.beta2;         // over the stored x^+, which is not needed any more
+            a.z0 = s.z_a; a.beta0 = s.beta_a;
+            a.z0_out = s.z_a; a.beta0_out = s.beta_a;
+            a.bdiv = acc_factor;
+            a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
+            a.c1 = k2.c1; a.c2 = k2.c2; a.om_rho = k2.om_rho; a.rho = k2.rho;
+            DS_CHECK(launch_acc_cone(acc_factor != 1.0 ? 3 : 1, s.g, lc, s.fg, a, s.st));
+        }
+        if (fold || post) {
             std::swap(s.z, s.z_p);                         // the cone pass wrote the new state there
             std::swap(s.beta, s.beta2);
         } else {
@@ -275,7 +297,7 @@ int Solver::acc_step(bool *brk) {
             DS_CHECK(launch_acc_interp(s.beta, s.beta2, s.beta_a, 10 * g.Nz, k2, mode, write_aux, s.st));
         }
     }
-    acc_gather_valid = fold;
+    acc_gather_valid = fold || post;
     prof_end(PH_INTERP);
     acc_k += 1;                                             // :381,413
     if (acc_k >= acc_restart) {                             // :385-388,417-418

@@ -131,3 +131,38 @@ def test_time_slabs_match_single_slab(case, nslabs, tsolve, monkeypatch):
     assert abs(sn - s1) <= 1e-12 * s1
     errs = {f: _relerr(getattr(got, f), getattr(ref, f)) for f in FIELDS}
     assert max(errs.values()) <= (1e-8 if weight is not None else 1e-10), errs
+
+
+@pytest.mark.parametrize("case", ["halpern", "restart5", "weighted", "slabs3"])
+def test_post_kkt_cone_pass_changes_nothing(case, monkeypatch):
+    """Halpern iterations that end with a KKT check: z and beta are extrapolated by ONE cone pass (k_acc_cone modes 1 / 3:
+    x^+ recomputed from the untouched state, the sigma factor applied on the way, the anchors stored, the next gather
+    emitted) instead of two scalings, two anchor copies, two extrapolation passes and a gather pass
+    (DOTSOCP_ACC_POST=0).  Same arithmetic in the same order: bit-identical."""
+    n, nt, K = 32, 16, 70
+    rho0, rho1 = get_example_2d("example1", n, n)
+    opts, weight, ns = dict(tol=0.0, maxit=K), None, 1
+    if case == "restart5":
+        opts.update(restart=5, rho=1.7)
+    if case == "weighted":
+        barrier = gene_barrier_of_circle_pillar()
+        weight = get_weight_by_barrier(n, n, nt, barrier)
+        rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    if case == "slabs3":
+        ns = 3
+    res = []
+    for post in ("1", "0"):
+        monkeypatch.setenv("DOTSOCP_ACC_POST", post)
+        var, model = D.initialize(rho0, rho1, nt)
+        if weight is not None:
+            model.weight = np.asarray(weight, dtype=np.float64)
+        oo = OD.default_opts(opts, "acc-ADMM", weight is not None)
+        D.InitialScaling(var, model, oo["scaling"], None, dim=2, weighted=weight is not None)
+        solve = D.solver_wsocp_accADMM if weight is not None else D.solver_socp_accADMM
+        hist, sigma = solve(var, oo, model, nslabs=ns)
+        res.append((var, hist, sigma))
+    (a, ha, sa), (b, hb, sb) = res
+    assert sa == sb
+    np.testing.assert_array_equal(ha["kkt"], hb["kkt"])
+    for f in FIELDS:
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
