@@ -25,7 +25,7 @@ namespace dotsocp {
 
 enum { ACC_RAW = 0, ACC_FUSED = 1, ACC_GATHER = 2, ACC_RESTART = 3 };
 
-template <int MODE, int XB>
+template <int MODE, int XB, bool NT = false>
 __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArgs a) {
     __shared__ double2 xch[2][XB][64];
     const int lane = threadIdx.x, xl = threadIdx.y;
@@ -52,9 +52,9 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
             const i64 i = yc + g.py * (xc + g.nx * tl);
             double b[10], zz[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+            for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nz + i);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) zz[j] = a.z_in[j * g.Nz + i];
+            for (int j = 0; j < 10; ++j) zz[j] = ld_stream<NT>(a.z_in + j * g.Nz + i);
             if (MODE == ACC_GATHER) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) w[j] = zz[j] + b[j];
@@ -74,15 +74,15 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                 if (MODE == ACC_RAW) {
                     if (own && inb) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = bp[j];
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, bp[j]);
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = v[j];
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nz + i, v[j]);
                     }
                 } else {
                     double zn[10], bn[10];
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
-                        const double z0 = (MODE == ACC_RESTART) ? v[j] : a.z0[j * g.Nz + i];
+                        const double z0 = (MODE == ACC_RESTART) ? v[j] : ld_stream<NT>(a.z0 + j * g.Nz + i);
                         double t = a.om_rho * zz[j];
                         t = t + a.rho * v[j];
                         zn[j] = a.c1 * z0 + a.c2 * t;
@@ -96,21 +96,21 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                     }
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
-                        const double b0 = (MODE == ACC_RESTART) ? bp[j] : a.beta0[j * g.Nz + i];
+                        const double b0 = (MODE == ACC_RESTART) ? bp[j] : ld_stream<NT>(a.beta0 + j * g.Nz + i);
                         double t = a.om_rho * b[j];
                         t = t + a.rho * bp[j];
                         bn[j] = a.c1 * b0 + a.c2 * t;
                     }
                     if (own && inb) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zn[j];
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nz + i, zn[j]);
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = bn[j];
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, bn[j]);
                         if (MODE == ACC_RESTART) {
 #pragma unroll
-                            for (int j = 0; j < 10; ++j) a.z0_out[j * g.Nz + i] = v[j];
+                            for (int j = 0; j < 10; ++j) st_stream<NT>(a.z0_out + j * g.Nz + i, v[j]);
 #pragma unroll
-                            for (int j = 0; j < 10; ++j) a.beta0_out[j * g.Nz + i] = bp[j];
+                            for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta0_out + j * g.Nz + i, bp[j]);
                         }
                     }
 #pragma unroll
@@ -133,11 +133,15 @@ int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom 
     a.TC = fg.TC;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)fg.chunks);
     dim3 blk(64, 4);
+    const bool nt = stream_nt_enabled();
+#define ACC_MODE(M)                                                                    \
+    case M:                                                                            \
+        if (nt) DS_KLAUNCH((k_acc_cone<M, 4, true>), grid, blk, 0, st, g, c, a);       \
+        else DS_KLAUNCH((k_acc_cone<M, 4>), grid, blk, 0, st, g, c, a);                \
+        break;
     switch (mode) {
-        case ACC_RAW: DS_KLAUNCH((k_acc_cone<ACC_RAW, 4>), grid, blk, 0, st, g, c, a); break;
-        case ACC_FUSED: DS_KLAUNCH((k_acc_cone<ACC_FUSED, 4>), grid, blk, 0, st, g, c, a); break;
-        case ACC_GATHER: DS_KLAUNCH((k_acc_cone<ACC_GATHER, 4>), grid, blk, 0, st, g, c, a); break;
-        case ACC_RESTART: DS_KLAUNCH((k_acc_cone<ACC_RESTART, 4>), grid, blk, 0, st, g, c, a); break;
+        ACC_MODE(ACC_RAW) ACC_MODE(ACC_FUSED) ACC_MODE(ACC_GATHER) ACC_MODE(ACC_RESTART)
+#undef ACC_MODE
         default: set_error("bad acc cone mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());

@@ -46,6 +46,21 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// Streams that are read or written exactly once per pass and are far larger than the caches (the cone multipliers: 10 Nz
+// doubles in, 10 Nz out): non-temporal accesses keep them from displacing the lines neighbouring tiles share (q edges,
+// tile-border partial sums).  Cone kernel at 1024 x 1024 x 128: 5.87 -> 5.50 ms.  (The q-step's alpha / q2 / q streams:
+// no effect, measured; its loads of neighbour tiles' entries rely on the L2.  The pipelined DCT kernels with `nt` on
+// their LDS-DMA loads and stores: 2.50 -> 2.60 ms at 1024-point lines, 3.1 -> 5.3 ms at 2048 -- tiles narrower than a
+// 128-byte line share every line with a neighbour workgroup.)
+template <bool NT>
+__device__ __forceinline__ double ld_stream(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void st_stream(double *p, double v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+bool stream_nt_enabled();          // fused.hip: DOTSOCP_NT=0 switches the non-temporal flavours off
+
 // Row projection onto {x1 >= ||x_2..K||}; literal restatement of mexProjSoc's arithmetic
 // (SURVEY.md 8a a1): n = ||x_2..K||, c = clamp((x1/n + 1)/2, 0, 1) with NaN passing through,
 // x_j <- c x_j, x_1 <- (c >= 1) ? x_1 : c n.

@@ -6,7 +6,8 @@
 //     beta^k   = beta_in + tau (z^k - (BF q + d))      multiplier step of iteration k-1     (:212-215)
 //     z^{k+1}  = Pi_Q(BF q + d - beta^k)               z-step of iteration k                (:199)
 //     q2       = F* B* (z^{k+1} + beta^k)              adjoint gather for the q-step        (:205)
-//   traffic: beta in + beta out + q_old + q + q2 = 8 (20 Nz + 3 Nq) bytes.
+//   traffic: beta in + beta out + q_old + q + q2 = 8 (20 Nz + 3 Nq) bytes; the beta streams non-temporal (device_utils.h:
+//   ld_stream / st_stream; the cell entries of q and the gather's stores the same way: no further gain, measured).
 //   MODE_A: same without the deferred update (beta already current): 8 (10 Nz + 2 Nq) bytes.
 //   MODE_M (2): materialise -- beta update + write z (needed by the rescale block / outputs).
 //   MODE_Z (3): z = Pi_Q(BF q_old + d - beta_in) only (z of the last iteration from the kept beta^k).
@@ -31,7 +32,7 @@
 
 namespace dotsocp {
 
-template <int MODE, int XB>
+template <int MODE, int XB, bool NT = false>
 __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, FusedArgs a) {
     __shared__ double2 xch[2][XB][64];
     const int lane = threadIdx.x, xl = threadIdx.y;
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
             double b[10], v[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+            for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nz + i);
             if (a.bpend) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
@@ -86,11 +87,11 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
                 if (own && inb) {
                     if (MODE != 3) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, b[j]);
                     }
                     if (MODE == 2 || MODE == 3) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) a.z_out[j * g.Nz + i] = zo[j];
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nz + i, zo[j]);
                     }
                 }
                 curo = nxto;
@@ -117,6 +118,11 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blk.y, blk.x,
                             a.q2, a.sx, a.sy);
     }
+}
+
+bool stream_nt_enabled() {
+    static const bool on = !(getenv("DOTSOCP_NT") && atoi(getenv("DOTSOCP_NT")) == 0);
+    return on;
 }
 
 bool tile_xcd_remap(const Grid &g) {
@@ -162,12 +168,15 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
     a.xcd = tile_xcd_remap(g) ? 1 : 0;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(64, 4);
+    const bool nt = stream_nt_enabled();
+#define CONE_MODE(M)                                                                     \
+    case M:                                                                              \
+        if (nt) DS_KLAUNCH((k_cone_fused<M, 4, true>), grid, blk, 0, st, g, c, a);       \
+        else DS_KLAUNCH((k_cone_fused<M, 4>), grid, blk, 0, st, g, c, a);                \
+        break;
     switch (mode) {
-        case 0: DS_KLAUNCH((k_cone_fused<0, 4>), grid, blk, 0, st, g, c, a); break;
-        case 1: DS_KLAUNCH((k_cone_fused<1, 4>), grid, blk, 0, st, g, c, a); break;
-        case 2: DS_KLAUNCH((k_cone_fused<2, 4>), grid, blk, 0, st, g, c, a); break;
-        case 3: DS_KLAUNCH((k_cone_fused<3, 4>), grid, blk, 0, st, g, c, a); break;
-        case 4: DS_KLAUNCH((k_cone_fused<4, 4>), grid, blk, 0, st, g, c, a); break;
+        CONE_MODE(0) CONE_MODE(1) CONE_MODE(2) CONE_MODE(3) CONE_MODE(4)
+#undef CONE_MODE
         default: set_error("bad fused mode"); return DOTSOCP_EINVAL;
     }
     DS_HIP(hipGetLastError());

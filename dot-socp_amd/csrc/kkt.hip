@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
 //
 // NORMS = true: only ||z||^2 and ||beta'||^2 of the iterate whose multiplier step is still pending, nothing stored (the
 // rescale block's every-100-iterations check, solver_socp_inPALM.m:139-149, when no KKT check precedes it).
-template <bool WEIGHTED, bool EDGES, bool NORMS = false>
+template <bool WEIGHTED, bool EDGES, bool NORMS = false, bool NT = false>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c, KktCoef k, FusedArgs a,
                                                                const double *__restrict__ phi,
                                                                const double *__restrict__ alpha,
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 const double q0 = a.q[i];
                 double v[10], zo[10];
 #pragma unroll
-                for (int j = 0; j < 10; ++j) b[j] = a.beta_in[j * g.Nz + i];
+                for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nz + i);
                 if (a.bpend) {
 #pragma unroll
                     for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 }
                 if (own && !NORMS) {
 #pragma unroll
-                    for (int j = 0; j < 10; ++j) a.beta_out[j * g.Nz + i] = b[j];
+                    for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, b[j]);
                     // ||z - Pi_Q(z - sigma beta')||^2 (:240-241) with proj_row's arithmetic, the projected row never
                     // stored: x = z - sigma beta' is cheap to form twice, ten registers are not
                     auto xj = [&](int j) { return zo[j] - k.sigma * b[j]; };
@@ -607,8 +607,14 @@ int launch_kkt_cells_update(const Grid &g, const LoopCoef &c, const KktCoef &k, 
         DS_HIP(hipGetLastError());
         return 0;
     }
-    if (weight) DS_KLAUNCH((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
-    else DS_KLAUNCH((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    const bool nt = stream_nt_enabled();
+    if (weight) {
+        if (nt) DS_KLAUNCH((k_kkt_cells<true, true, false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        else DS_KLAUNCH((k_kkt_cells<true, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    } else {
+        if (nt) DS_KLAUNCH((k_kkt_cells<false, true, false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+        else DS_KLAUNCH((k_kkt_cells<false, true>), grid, blk, 0, st, g, c, k, a, phi, alpha, weight, part);
+    }
     DS_HIP(hipGetLastError());
     for (int dir = 0; dir < 2; ++dir) {
         const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;
