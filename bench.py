@@ -322,6 +322,10 @@ def main():
         # multiplier + z-step + Halpern step of z, beta + next adjoint sums: z, beta, anchors in, z, beta out
         kname, (proj_ms, proj_n) = "k_acc_cone<1,4> (multiplier + projection + Halpern + gather)", times["acc_cone"]
         alg_bytes = 8.0 * (60 * Nz + 2 * Nq)
+    elif args.method == "PALM" and times["cone_fused_b"][1] > 0:
+        # one pass over beta per iteration: beta in + out, q~^{k-1}, q^k, q~^k in, two adjoint gathers out
+        kname, (proj_ms, proj_n) = "k_cone_fused<5,4> (beta update + cone projection + two adjoint gathers)", times["cone_fused_b"]
+        alg_bytes = 8.0 * (20 * Nz + 5 * Nq)
     elif args.method == "PALM":
         kname, (proj_ms, proj_n) = "k_cone_fused<0,4> (cone projection + adjoint gather)", times["cone_fused_a"]
         alg_bytes = 8.0 * (10 * Nz + 2 * Nq)
@@ -360,7 +364,7 @@ def main():
                 "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
     kernels = [r for r in (
-        krow(kname, alg_bytes, {"acc-ADMM": "acc_cone", "PALM": "cone_fused_a"}.get(args.method, "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_proj")),
+        krow(kname, alg_bytes, {"acc-ADMM": "acc_cone", "PALM": "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_fused_a"}.get(args.method, "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_proj")),
         krow("k_qstep_rhs (A phi, q-step, alpha update, next rhs)", 8.0 * (3 * Nphi + 4 * Nq), "qstep"),
         krow("Poisson solve: y, x forward, fused t pass, x, y inverse (five launches; k_dct_* / k_pfa_*)", 8.0 * 10 * Nphi,
              "poisson", 5),

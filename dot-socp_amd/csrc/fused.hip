@@ -13,6 +13,11 @@
 //   MODE_Z (3): z = Pi_Q(BF q_old + d - beta_in) only (z of the last iteration from the kept beta^k).
 //   MODE_P (4): PALM's extra q-step (solver_socp_PALM.m:196-200): deferred beta update as in MODE_B, then
 //               q2 = F* B* (z^k + beta^k) with the recomputed z^k -- no new projection.
+//   MODE_P2 (5), MODE_P1 (6): PALM with ONE pass over beta per iteration (solver_palm.hip).  Mode 6 is MODE_A, mode 5 is MODE_B
+//               with the new projection taken at a third array, q3 = q~^k (PALM projects at BF q~ + d, :209, and updates the
+//               multiplier at BF q + d, :224); both emit a second gather p2 = F*B*((1 + tau) z^{k+1} + beta^k), from which
+//               the next iteration's first q-step forms F*B*(z^{k+1} + beta^{k+1}) = p2 - tau F*B*(BF q^{k+1} + d) without a
+//               pass over beta (F*B*BF is diagonal, F*B*d = 0).
 //   (line numbers: socp/dot2d/algorithms/solver_socp_inPALM.m)
 //
 // Mapping: a workgroup owns a 64 (y) x XB (x) tile of cell columns and MARCHES through a chunk
@@ -34,7 +39,11 @@ namespace dotsocp {
 
 template <int MODE, int XB, bool NT = false>
 __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, FusedArgs a) {
+    constexpr bool DUAL = (MODE >= 5);              // second gather (PALM)
+    constexpr bool UPD = (MODE != 0 && MODE != 6);  // deferred multiplier step in front of the projection
+    constexpr bool PROJ = (MODE < 2 || MODE >= 5);  // new projection + gather
     __shared__ double2 xch[2][XB][64];
+    __shared__ double2 xchp[DUAL ? 2 : 1][DUAL ? XB : 1][DUAL ? 64 : 1];
     const int lane = threadIdx.x, xl = threadIdx.y;
     const BlockId blk = block_id(a.xcd != 0);
     const i64 y = (i64)blk.x * 64 + lane;
@@ -44,19 +53,20 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
     const i64 t0 = ((i64)blk.z + a.z0) * a.TC;
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
     const bool lastChunk = (t1 == g.ncl);
-    constexpr bool GATHER = (MODE < 2 || MODE == 4);
+    constexpr bool GATHER = (PROJ || MODE == 4);
     const i64 tstart = (GATHER && t0 > 0) ? t0 - 1 : t0;
     const i64 nxblk = gridDim.y, nyblk = gridDim.x;
 
-    EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo;
-    if (MODE != 0) curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
-    GatherCarry gc;
+    EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo, cur3;
+    if (UPD) curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
+    if (MODE == 5) cur3 = load_edges(g, a.q3, yc, xc, tstart, c.sf);
+    GatherCarry gc, gcp;
     // one extra virtual step (tl == ncl, no cell) on the last chunk emits the final edge layer
     const i64 tstop = (GATHER && lastChunk) ? t1 + 1 : t1;
     for (i64 tl = tstart; tl < tstop; ++tl) {
         const bool hasCell = tl < g.ncl;
         const bool own = tl >= t0;                      // false only for the recomputed cell in front of the chunk
-        double w[10];
+        double w[10], wp[10];
         if (hasCell) {
             const i64 i = yc + g.py * (xc + g.nx * tl);
             const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
@@ -72,7 +82,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
                 }
             }
             build_z2(v, a.q[i], cur, nxt, c.s, c.dF);
-            if (MODE != 0) {
+            if (UPD) {
                 const EdgeQuad nxto = load_edges(g, a.q_old, yc, xc, tl + 1, c.sf);
                 double zo[10];
                 build_z2(zo, a.q_old[i], curo, nxto, c.s, c.dF);
@@ -102,21 +112,44 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
                 }
             }
             cur = nxt;
-            if (MODE < 2) {
+            if (PROJ) {
+                if (MODE == 5) {          // the projection's argument is BF q3 + d
+                    const EdgeQuad nxt3 = load_edges(g, a.q3, yc, xc, tl + 1, c.sf);
+                    build_z2(v, a.q3[i], cur3, nxt3, c.s, c.dF);
+                    cur3 = nxt3;
+                }
 #pragma unroll
                 for (int j = 0; j < 10; ++j) v[j] = v[j] - b[j];
                 proj_row<10>(v);
 #pragma unroll
                 for (int j = 0; j < 10; ++j) w[j] = v[j] + b[j];
                 if (own && inb) a.q2[i] = c.s * (w[9] - w[0]);
+                if (DUAL) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) wp[j] = w[j] + c.tau * v[j];
+                    if (own && inb) a.p2[i] = c.s * (wp[9] - wp[0]);
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 10; ++j) w[j] = 0.0;
+            if (DUAL) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) wp[j] = 0.0;
+            }
         }
-        if (GATHER)   // adjoint gather for edge layer tl (gather_tile.h)
+        if constexpr (GATHER && !DUAL)   // adjoint gather for edge layer tl (gather_tile.h)
             gather_emit<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blk.y, blk.x,
                             a.q2, a.sx, a.sy);
+        if constexpr (DUAL) {            // two gathers, one barrier
+            gather_post<XB>(xch, gc, w, xl, lane);
+            gather_post<XB>(xchp, gcp, wp, xl, lane);
+            __syncthreads();
+            gather_finish<XB>(g, c.sf, xch, gc, w, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blk.y, blk.x,
+                              a.q2, a.sx, a.sy);
+            gather_finish<XB>(g, c.sf, xchp, gcp, wp, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blk.y, blk.x,
+                              a.p2, a.sxp, a.syp);
+        }
     }
 }
 
@@ -175,7 +208,7 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
         else DS_KLAUNCH((k_cone_fused<M, 4>), grid, blk, 0, st, g, c, a);                \
         break;
     switch (mode) {
-        CONE_MODE(0) CONE_MODE(1) CONE_MODE(2) CONE_MODE(3) CONE_MODE(4)
+        CONE_MODE(0) CONE_MODE(1) CONE_MODE(2) CONE_MODE(3) CONE_MODE(4) CONE_MODE(5) CONE_MODE(6)
 #undef CONE_MODE
         default: set_error("bad fused mode"); return DOTSOCP_EINVAL;
     }

@@ -18,14 +18,20 @@ struct GatherCarry {
     int par = 0;
 };
 
+// the two halves of gather_emit: the LDS hand-off in front of the workgroup barrier, everything else behind it (a kernel
+// with two gathers per step posts both, waits once, finishes both)
 template <int XB>
-__device__ __forceinline__ void gather_emit(const Grid &g, double sf, double2 (&xch)[2][XB][64], GatherCarry &gc,
+__device__ __forceinline__ void gather_post(double2 (&xch)[2][XB][64], const GatherCarry &gc, const double (&w)[10], int xl,
+                                            int lane) {
+    xch[gc.par][xl][lane] = make_double2(w[1], gc.p3);
+}
+
+template <int XB>
+__device__ __forceinline__ void gather_finish(const Grid &g, double sf, double2 (&xch)[2][XB][64], GatherCarry &gc,
                                             const double (&w)[10], i64 tl, bool store, i64 x, i64 y, int xl,
                                             int lane, i64 nxblk, i64 nyblk, unsigned bx_blk, unsigned by_blk,
                                             double *__restrict__ q2, double *__restrict__ sx,
                                             double *__restrict__ sy) {
-    xch[gc.par][xl][lane] = make_double2(w[1], gc.p3);
-    __syncthreads();
     if (store) {
         if (x < g.nx - 1) {
             const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
@@ -58,6 +64,17 @@ __device__ __forceinline__ void gather_emit(const Grid &g, double sf, double2 (&
     }
     gc.p3 = w[3]; gc.p4 = w[4]; gc.p7 = w[7]; gc.p8 = w[8];
     gc.par ^= 1;
+}
+
+template <int XB>
+__device__ __forceinline__ void gather_emit(const Grid &g, double sf, double2 (&xch)[2][XB][64], GatherCarry &gc,
+                                            const double (&w)[10], i64 tl, bool store, i64 x, i64 y, int xl,
+                                            int lane, i64 nxblk, i64 nyblk, unsigned bx_blk, unsigned by_blk,
+                                            double *__restrict__ q2, double *__restrict__ sx,
+                                            double *__restrict__ sy) {
+    gather_post<XB>(xch, gc, w, xl, lane);
+    __syncthreads();
+    gather_finish<XB>(g, sf, xch, gc, w, tl, store, x, y, xl, lane, nxblk, nyblk, bx_blk, by_blk, q2, sx, sy);
 }
 
 }  // namespace dotsocp

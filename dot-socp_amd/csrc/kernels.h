@@ -64,6 +64,8 @@ struct FusedArgs {
     double *z_out;          // mode 2
     double *q2;             // modes 0, 1: adjoint sums, q layout
     double *sx, *sy;        // modes 0, 1: tile-boundary partial sums
+    const double *q3;       // mode 5: q~^k, the argument of the new projection (q then is q^k of the multiplier step)
+    double *p2, *sxp, *syp; // modes 5, 6: second gather, F*B*((1 + tau) z + beta), layout of q2 / sx / sy
     i64 TC;
     // pending scaling of beta_in (sigma update / rescale block, solver_socp_inPALM.m:176,313), applied on
     // load exactly like k_scale would have: b = b * bmul / bdiv
@@ -164,7 +166,8 @@ int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, do
 // PALM (solver_socp_PALM.m:196-200,137): first q-step without the alpha update; tmp_q = A phi in q layout
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                             const double *sx, const double *sy, const double *cvec, double *q_out, const double *alpha,
-                            double *rhs, hipStream_t st, const double *tail_bx = nullptr, const double *tail_by = nullptr);
+                            double *rhs, hipStream_t st, const double *tail_bx = nullptr, const double *tail_by = nullptr,
+                            const double *qk = nullptr);   // qk: q2 / sx / sy hold k_cone_fused's second gather (modes 5, 6)
 int launch_grad(const Grid &g, const LoopCoef &c, const double *phi, double *out, hipStream_t st);
 // time-slab mode: complete the adjoint sums of the last owned cell for the right neighbour (values times sf)
 int launch_tail_finalize(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *q2, const double *sx,

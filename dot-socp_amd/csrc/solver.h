@@ -86,6 +86,7 @@ struct Slab {
     KktWork kw{};
     // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
     double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
+    double *q3 = nullptr, *p2 = nullptr, *sxp = nullptr, *syp = nullptr;    // PALM, one pass over beta per iteration (solver_palm.hip)
     double *alpha2 = nullptr;   // ping-pong partner of alpha (q-step that also forms the next rhs)
     // partitioned tridiagonal t-solve (tri.hip): messages to / from the owners of the modes, zero-mode work line
     double *tri_send = nullptr, *tri_recv = nullptr, *tri_bsend = nullptr, *tri_brecv = nullptr, *tri_zero = nullptr;
@@ -295,6 +296,8 @@ struct Solver {
                         double *bx, double *by);
     int jump_from(Solver &coarse);
     // PALM (solver_palm.hip)
+    bool palm_fast = true;     // one slab: one pass over beta per iteration (DOTSOCP_PALM_FAST=0: the two-pass dataflow)
+    bool palm_p_valid = false; // p2 / sxp / syp hold the second gather of the last cone pass
     int palm_begin();
     int palm_step(bool *brk);
 };

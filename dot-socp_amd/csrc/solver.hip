@@ -170,6 +170,7 @@ void Solver::free_slabs() {
         dfree(s.send_plane); dfree(s.send_plane2); dfree(s.send_bx); dfree(s.send_by);
         dfree(s.kw.partials); dfree(s.kw.sums);
         dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy); dfree(s.alpha2);
+        dfree(s.q3); dfree(s.p2); dfree(s.sxp); dfree(s.syp);
         dfree(s.tri_send); dfree(s.tri_recv); dfree(s.tri_bsend); dfree(s.tri_brecv); dfree(s.tri_zero);
         dfree(s.phi_p); dfree(s.alpha_p); dfree(s.z_p);
         dfree(s.phi_a); dfree(s.q_a); dfree(s.alpha_a); dfree(s.z_a); dfree(s.beta_a);

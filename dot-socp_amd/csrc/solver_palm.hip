@@ -13,6 +13,17 @@
 //   pass 2  k_cone_fused<0>: z^{k+1} = Pi(BF q~^k + d - beta^k), q2 = F*B*(z^{k+1} + beta^k) (:209-210,216)
 //   q^{k+1}, alpha^{k+1}                                      -> s.q                       (:215-217,221,225)
 //   beta^{k+1}: deferred to pass 1 of the next iteration (or to the KKT block)              (:222-226)
+//
+// One slab (palm_fast): ONE pass over beta per iteration.  F*B*BF is diagonal and F*B*d = 0, so the gather of pass 1,
+//   F*B*(z^k + beta^k) = F*B*((1 + tau) z^k + beta^{k-1}) - tau F*B*(BF q^k + d),
+// needs no pass over beta: the cone pass of iteration k-1 emits p2 = F*B*((1 + tau) z^k + beta^{k-1}) as a second gather
+// beside the q2 of its own q-step (k_cone_fused modes 5 / 6), and the first q-step of iteration k subtracts the
+// element-wise term (k_qstep_rhs VAR 3 with qk).  The multiplier step then waits for the cone pass of iteration k, which
+// recomputes z^k from q~^{k-1} (kept: q~ alternates between q_old and q3), updates beta with q^k and projects at q~^k:
+//   pass    k_cone_fused<5>: z^k = Pi(BF q~^{k-1} + d - beta^{k-1}), beta^k = beta^{k-1} + tau (z^k - BF q^k - d) stored,
+//           z^{k+1} = Pi(BF q~^k + d - beta^k), q2 = F*B*(z^{k+1} + beta^k), p2 = F*B*((1 + tau) z^{k+1} + beta^k)
+// Right after a KKT or rescale block (multiplier step executed, z regenerated on demand) the iteration runs as above with
+// mode 6 (= mode 0 + p2) as its pass 2.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -43,6 +54,17 @@ int Solver::palm_begin() {
     FOR_SLABS(s) DS_CHECK(launch_bfd(s.g, s.z, s.q2, lc.s, lc.dF, s.st));
     deferred = false;
     z_valid = true;
+    if (const char *e = getenv("DOTSOCP_PALM_FAST")) palm_fast = (atoi(e) != 0);
+    palm_p_valid = false;
+    if (palm_fast && !multi()) {
+        FOR_SLABS(s) {
+            if (s.q3) continue;
+            DS_CHECK(dzalloc(&s.q3, s.g.NqAlloc, s.st));
+            DS_CHECK(dzalloc(&s.p2, s.g.NqAlloc, s.st));
+            DS_CHECK(dzalloc(&s.sxp, s.fg.sx_len, s.st));
+            DS_CHECK(dzalloc(&s.syp, s.fg.sy_len, s.st));
+        }
+    }
     return 0;
 }
 
@@ -52,7 +74,14 @@ int Solver::palm_step(bool *brk) {
     DS_CHECK(rescale_block());            // :142-194 (scales phi in place of tmp_q for this method)
     // ---- first q-step :196-200 ----
     prof_begin(PH_QSTEP0);
-    if (deferred) {
+    const bool fast = palm_fast && !multi();
+    // the gather comes from the last cone pass's second output; the multiplier step stays pending until this iteration's pass
+    const bool three = fast && deferred && palm_p_valid;
+    if (three) {
+        FOR_SLABS(s)
+            DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.p2, s.sxp, s.syp, s.c, s.q3, s.alpha, s.w0, s.st, nullptr,
+                                             nullptr, s.q));
+    } else if (deferred) {
         FOR_SLABS(s) {
             FusedArgs a{};
             a.q_old = s.q_old; a.q = s.q;
@@ -74,10 +103,12 @@ int Solver::palm_step(bool *brk) {
             DS_CHECK(launch_acc_cone(2, s.g, lc, s.fg, a, s.st));
         }
     }
-    DS_CHECK(phase_z_tails());            // time slabs: adjoint tails -> right (the phi head travelled in the last iteration)
-    FOR_SLABS(s)
-        DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, s.st,
-                                         s.tail_bx, s.tail_by));
+    if (!three) {
+        DS_CHECK(phase_z_tails());        // time slabs: adjoint tails -> right (the phi head travelled in the last iteration)
+        FOR_SLABS(s)
+            DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.q2, s.sx, s.sy, s.c, s.q_old, s.alpha, s.w0, s.st,
+                                             s.tail_bx, s.tail_by));
+    }
     prof_end(PH_QSTEP0);
     if (multi()) {
         // q~ halo -> left (projection of the last cell layer), u0 = q~0 - alpha0 of the last cell -> right (first rhs layer)
@@ -97,15 +128,29 @@ int Solver::palm_step(bool *brk) {
     DS_CHECK(poisson_all());
     prof_end(PH_POISSON);
     // ---- step z :207-211 (+ the adjoint sums of :216) ----
-    prof_begin(PH_FUSED_A);
+    prof_begin(three ? PH_FUSED_B : PH_FUSED_A);
     FOR_SLABS(s) {
         FusedArgs a{};
-        a.q = s.q_old;
-        a.beta_in = s.beta;
         a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
-        DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, s.st));
+        a.p2 = s.p2; a.sxp = s.sxp; a.syp = s.syp;
+        if (three) {
+            a.q_old = s.q_old;            // q~^{k-1}: z^k again
+            a.q = s.q;                    // q^k: the multiplier step
+            a.q3 = s.q3;                  // q~^k: the projection
+            a.beta_in = s.beta; a.beta_out = s.beta2;
+            set_pending(a);
+            DS_CHECK(launch_cone_fused(5, s.g, lc, s.fg, a, s.st));
+            std::swap(s.beta, s.beta2);
+            std::swap(s.q_old, s.q3);     // q_old = q~^k again, as the KKT / rescale blocks and the next pass expect
+        } else {
+            a.q = s.q_old;
+            a.beta_in = s.beta;
+            DS_CHECK(launch_cone_fused(fast ? 6 : 0, s.g, lc, s.fg, a, s.st));
+        }
     }
-    prof_end(PH_FUSED_A);
+    if (three) bpend = 0;
+    palm_p_valid = fast;
+    prof_end(three ? PH_FUSED_B : PH_FUSED_A);
     z_valid = false;
     z_prev_ok = false;
     DS_CHECK(phase_z_tails());            // time slabs: phi^{k+1} head -> left, adjoint tails -> right

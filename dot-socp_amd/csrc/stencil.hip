@@ -355,6 +355,21 @@ __device__ __forceinline__ double q_calc(const LoopCoef &c, double tmp, double q
     return a;
 }
 
+// F*B*(BF q + d) of one q entry, with mexBFd's / mexBFdConj's arithmetic: a q0 entry sits in columns 1 and 10 of its cell
+// (d cancels), a staggered edge in one column of each of the four cells around it -- two on the first and the last layer
+__device__ __forceinline__ double fbbf_cell(const LoopCoef &c, double q0) {
+    return c.s * ((c.dF + c.s * q0) - (c.dF - c.s * q0));
+}
+__device__ __forceinline__ double fbbf_edge(const LoopCoef &c, double e, bool tbnd) {
+    const double v = c.sf * e;
+    double acc = v + v;
+    if (!tbnd) {
+        acc += v;
+        acc += v;
+    }
+    return c.sf * acc;
+}
+
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
@@ -367,6 +382,9 @@ struct QRhsArgs {
     double c1, c2, om_rho, rho;
     APend ap;          // pending scaling of alpha_in (VAR 0)
     int xcd;           // XCD-aware tile order
+    // VAR 3 with the gather given as p2 = F*B*((1 + tau) z + beta) (k_cone_fused modes 5 / 6): qk = q^k, and the gather the
+    // q-step uses is p2 - tau F*B*(BF q^k + d)
+    const double *qk;
     // KKT variant (VAR 0, single slab): per-workgroup partial sums, r = A' alpha^+ - c per node, DOT complementarity scalars
     double *partials, *resid;
     double kappa, dsD;
@@ -458,7 +476,9 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
             double tmp = (-c.at) * a.phi[k];
             tmp += c.at * p0;
             double qn, an;
-            q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, a.q2v[k], c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev, a.ap);
+            double g0f = a.q2v[k];
+            if (VAR == 3 && a.qk) g0f = g0f - c.tau * fbbf_cell(c, a.qk[k]);
+            q_value<WEIGHTED, (VAR == 3 ? 2 : (VAR != 0 ? 1 : 0))>(c, tmp, g0f, c.c1, c.dinv1, k, a.weight, a.alpha_in, qn, an, u0prev, a.ap);
             if (KKT) {
                 a0prev = an;
                 rhoTprev = a.kappa * (wgt(k) * an);
@@ -502,8 +522,11 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
         const double pXl = ph[par][xl + 2][lane + 1];
         const double pYl = ph[par][xl + 1][lane + 2];
         const double al0 = a.alpha_in[k0], alX = a.alpha_in[eX], alY = a.alpha_in[eY];
-        const double g0 = a.q2v[k0];
+        double g0 = a.q2v[k0];
         double gX = a.q2v[eX], gY = a.q2v[eY];
+        double k0v = 0.0, kXv = 0.0, kYv = 0.0;
+        const bool pcorr = (VAR == 3) && (a.qk != nullptr);
+        if (pcorr) { k0v = a.qk[k0]; kXv = a.qk[eX]; kYv = a.qk[eY]; }
         const double cv = a.cvec[node];
         double w0 = 1.0, wX = 1.0, wY = 1.0;
         if (WEIGHTED) { w0 = a.weight[k0]; wX = a.weight[eX]; wY = a.weight[eY]; }
@@ -515,13 +538,14 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
             if (hasBy) tYv = a.tail_by[y + g.pyb * x];
         }
         // neighbour tiles' edges (first column / first row of the tile)
-        double pLl = 0.0, alL = 0.0, gL = 0.0, wL = 1.0, sxL = 0.0, tLv = 0.0;
+        double pLl = 0.0, alL = 0.0, gL = 0.0, wL = 1.0, sxL = 0.0, tLv = 0.0, kLv = 0.0, kBv = 0.0;
         i64 eL = 0;
         if (leftTile) {
             eL = g.offBx + g.bxLayer * tl + y + g.py * (x - 1);
             pLl = ph[par][0][lane + 1];
             alL = a.alpha_in[eL];
             gL = a.q2v[eL];
+            if (pcorr) kLv = a.qk[eL];
             if (WEIGHTED) wL = a.weight[eL];
             if (((x - 1) % fg.XB) == fg.XB - 1) sxL = a.sx[(tl * fg.nxblk + ((x - 1) / fg.XB + 1)) * g.ny + y];
             if (tails) tLv = a.tail_bx[y + g.py * (x - 1)];
@@ -533,6 +557,7 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
             pBl = ph[par][xl + 1][0];
             alB = a.alpha_in[eB];
             gB = a.q2v[eB];
+            if (pcorr) kBv = a.qk[eB];
             if (WEIGHTED) wB = a.weight[eB];
             if (((y - 1) & 63) == 63) syB = a.sy[(tl * g.nx + x) * fg.nyblk + ((y - 1) / 64 + 1)];
             if (tails) tBv = a.tail_by[(y - 1) + g.pyb * x];
@@ -542,6 +567,11 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
         if (sxOwn) gX = c.sf * (gX + sxv);
         if (syOwn) gY = c.sf * (gY + syv);
         if (tails) { gX += tXv; gY += tYv; }
+        if (pcorr) {
+            g0 = g0 - c.tau * fbbf_cell(c, k0v);
+            gX = gX - c.tau * fbbf_edge(c, kXv, tbnd);
+            gY = gY - c.tau * fbbf_edge(c, kYv, tbnd);
+        }
         double pT = 0.0, u0 = 0.0, ubx = 0.0, uby = 0.0;
         double a0 = 0.0, abx = 0.0, aby = 0.0;                 // KKT: alpha^+ of the own entries
         double qbx = 0.0, mbx = 0.0, qby = 0.0, mby = 0.0;     // KKT: q^+ and momentum kappa (w alpha^+) of the own edges
@@ -591,6 +621,7 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
             double q2 = gL;
             if (((x - 1) % fg.XB) == fg.XB - 1) q2 = c.sf * (q2 + sxL);
             if (tails) q2 += tLv;
+            if (pcorr) q2 = q2 - c.tau * fbbf_edge(c, kLv, tbnd);
             double tmp = (-c.ax) * pLl;
             tmp += c.ax * p0;
             double qn, an;
@@ -601,6 +632,7 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
             double q2 = gB;
             if (((y - 1) & 63) == 63) q2 = c.sf * (q2 + syB);
             if (tails) q2 += tBv;
+            if (pcorr) q2 = q2 - c.tau * fbbf_edge(c, kBv, tbnd);
             double tmp = (-c.ay) * pBl;
             tmp += c.ay * p0;
             double qn, an;
@@ -860,10 +892,10 @@ int launch_rhs_fixup(const Grid &g, const LoopCoef &c, const double *u0_prev, do
 // plus the rhs of the phi-step that follows it (:204), A'(q_out - alpha) + c
 int launch_qstep_palm_first(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                             const double *sx, const double *sy, const double *cvec, double *q_out, const double *alpha,
-                            double *rhs, hipStream_t st, const double *tail_bx, const double *tail_by) {
+                            double *rhs, hipStream_t st, const double *tail_bx, const double *tail_by, const double *qk) {
     QRhsArgs a{};
     a.phi = phi; a.q2v = q2; a.sx = sx; a.sy = sy; a.cvec = cvec; a.tail_bx = tail_bx; a.tail_by = tail_by;
-    a.alpha_in = alpha; a.q_out = q_out; a.rhs = rhs;
+    a.alpha_in = alpha; a.q_out = q_out; a.rhs = rhs; a.qk = qk;
     return launch_qstep_rhs_var(3, g, c, fg, a, st);
 }
 

@@ -92,3 +92,27 @@ def test_rejected_configurations():
     rho0, rho1 = get_example_1d("gaussian", 64)
     with pytest.raises(ValueError):
         D.solver_dotsocp1d(rho0, rho1, 16, 1, dict(tol=1e-3), "PALM")
+
+
+@pytest.mark.parametrize("ny,nx,nt,K", [(32, 32, 16, 70), (40, 24, 9, 45), (65, 33, 17, 30), (130, 70, 20, 24)])
+def test_one_pass_dataflow_equals_two_pass(ny, nx, nt, K, monkeypatch):
+    """One slab: one pass over beta per iteration -- the first q-step's gather F*B*(z^k + beta^k) is formed from the second
+    gather of the previous cone pass, F*B*((1 + tau) z^k + beta^{k-1}), minus tau F*B*(BF q^k + d) taken entry by entry
+    (k_cone_fused modes 5 / 6, k_qstep_rhs VAR 3 with qk) -- against the two-pass dataflow (DOTSOCP_PALM_FAST=0).  The
+    same algebra in another order of summation: 1e-11, over KKT checks, sigma updates and rescale blocks; tiles that are
+    cut by the grid (130 x 70), odd sizes."""
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    res = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("DOTSOCP_PALM_FAST", fast)
+        var, model = D.initialize(rho0, rho1, nt)
+        oo = OD.default_opts(dict(tol=0.0, maxit=K), "PALM", False)
+        D.InitialScaling(var, model, oo["scaling"], None, dim=2)
+        hist, sigma = D.solver_socp_PALM(var, oo, model)
+        res.append((var, hist, sigma))
+    (a, ha, sa), (b, hb, sb) = res
+    assert abs(sa - sb) <= 1e-13 * abs(sb)
+    np.testing.assert_array_equal(ha["iter"], hb["iter"])
+    np.testing.assert_allclose(ha["kkt"], hb["kkt"], rtol=1e-8, atol=1e-12)
+    errs = {f: _relerr(getattr(a, f), getattr(b, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-11, errs
