@@ -181,6 +181,32 @@ __global__ void __launch_bounds__(256) k_acc_interp(double *__restrict__ x, cons
     }
 }
 
+// Halpern extrapolation of one array right after a sigma update (:346-358 followed by :373-379 with k = 0): x and x^+ are
+// divided by the factor (alpha; div = 1 for phi and q), the anchor is x^+ itself -- stored -- and
+// x = c1 x^+ + c2 ((1-rho) x + rho x^+); k_scale's, the anchor copy's and k_acc_interp's arithmetic in one pass.
+__global__ void __launch_bounds__(256) k_acc_restart(double *__restrict__ x, const double *__restrict__ xp,
+                                                     double *__restrict__ anchor, i64 n, AccCoef k, double div, int use_div) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        double xo = x[i], xn = xp[i];
+        if (use_div) {
+            xo = xo / div;
+            xn = xn / div;
+        }
+        anchor[i] = xn;
+        double hat = k.om_rho * xo;
+        hat = hat + k.rho * xn;
+        x[i] = k.c1 * xn + k.c2 * hat;
+    }
+}
+
+int launch_acc_restart(double *x, const double *xp, double *anchor, i64 n, const AccCoef &k, double div, hipStream_t st) {
+    if (n <= 0) return 0;
+    DS_KLAUNCH(k_acc_restart, dim3(launch_blocks(n, 256, 1 << 22)), dim3(256), 0, st, x, xp, anchor, n, k, div,
+               (int)(div != 1.0));
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
                       hipStream_t st) {
     if (n <= 0) return 0;

@@ -106,6 +106,8 @@ struct AccCoef {
 // mode 0: multiplier + z-step, raw outputs; 1: + Halpern step + gather; 2: gather of (z + beta) only;
 // 3: mode 1 after a sigma update (beta, beta^+ divided by a.bdiv, anchors = x^+ stored)
 int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, AccArgs a, hipStream_t st);
+// Halpern step right after a sigma update: x, x^+ divided by div, anchor = x^+ stored, x extrapolated with k = 0
+int launch_acc_restart(double *x, const double *xp, double *anchor, i64 n, const AccCoef &k, double div, hipStream_t st);
 // element-wise extrapolation of one state array (modes: see acc.hip)
 int launch_acc_interp(double *x, const double *xp, double *aux, i64 n, const AccCoef &k, int mode, int write_aux,
                       hipStream_t st);

@@ -1069,7 +1069,7 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
     FOR_SLABS(s) {
         const Grid &g = s.g;
         if (with_c) DS_CHECK(launch_scale(s.c, g.Nphi, a_mul, a_div, s.st));
-        DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, s.st));
+        if (!acc_light) DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, s.st));
         // (acc_light: acc-ADMM's sigma update with the extrapolating cone pass to follow, which divides beta itself)
         if (!(fused && begun) && !acc_light) DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, s.st));
         if (q_div != 1.0) {

@@ -58,7 +58,6 @@ int Solver::acc_set_anchors() {
         DS_HIP(cp(s.phi_a, s.phi, g.NphiAlloc));
         DS_HIP(cp(s.q_a, s.q, g.NqAlloc));
         DS_HIP(cp(s.alpha_a, s.alpha, g.NqAlloc));
-        if (acc_light) continue;                 // z, beta: k_acc_cone<ACC_RESTART> stores their anchors
         DS_HIP(cp(s.z_a, s.z, 10 * g.Nz));
         DS_HIP(cp(s.beta_a, s.beta, 10 * g.Nz));
     }
@@ -93,12 +92,15 @@ void Solver::acc_swap_state() {
 // :346-358, called from kkt_block() with the pointers swapped: scale_state() has divided alpha^+, beta^+, c;
 // here the previous iterates follow and the extrapolation restarts from x^+
 int Solver::acc_on_sigma_factor(double factor) {
-    FOR_SLABS(s) {
-        DS_CHECK(launch_scale(s.alpha_p, s.g.NqAlloc, 1.0, factor, s.st));
-        if (!acc_light) DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, s.st));
-    }
     acc_factor = factor;
     acc_k = 0;
+    // acc_light: the previous iterates, the anchors and the extrapolation take one pass per array after the block
+    // (k_acc_restart, k_acc_cone<ACC_RESTART>), which divides on the way
+    if (acc_light) return 0;
+    FOR_SLABS(s) {
+        DS_CHECK(launch_scale(s.alpha_p, s.g.NqAlloc, 1.0, factor, s.st));
+        DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, s.st));
+    }
     if (acc_halpern) DS_CHECK(acc_set_anchors());
     return 0;
 }
@@ -272,8 +274,15 @@ int Solver::acc_step(bool *brk) {
     const int write_aux = (!acc_halpern && acc_k + 1 < acc_restart) ? 1 : 0;      // :417-421
     FOR_SLABS(s) {
         const Grid &g = s.g;
-        DS_CHECK(launch_acc_interp(s.phi, s.phi_p, s.phi_a, g.Nphi, k2, mode, write_aux, s.st));
-        if (!fold) {
+        const bool restart = post && acc_factor != 1.0;
+        if (restart) {
+            DS_CHECK(launch_acc_restart(s.phi, s.phi_p, s.phi_a, g.Nphi, k2, 1.0, s.st));
+            DS_CHECK(launch_acc_restart(s.q, s.q_old, s.q_a, g.NqAlloc, k2, 1.0, s.st));
+            DS_CHECK(launch_acc_restart(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, acc_factor, s.st));
+        } else {
+            DS_CHECK(launch_acc_interp(s.phi, s.phi_p, s.phi_a, g.Nphi, k2, mode, write_aux, s.st));
+        }
+        if (!fold && !restart) {
             DS_CHECK(launch_acc_interp(s.q, s.q_old, s.q_a, g.NqAlloc, k2, mode, write_aux, s.st));
             DS_CHECK(launch_acc_interp(s.alpha, s.alpha_p, s.alpha_a, g.NqAlloc, k2, mode, write_aux, s.st));
         }
