@@ -154,8 +154,8 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
 }
 
 bool stream_nt_enabled() {
-    static const bool on = !(getenv("DOTSOCP_NT") && atoi(getenv("DOTSOCP_NT")) == 0);
-    return on;
+    const char *e = getenv("DOTSOCP_NT");          // read per launch: the tests switch it inside one process
+    return !(e && atoi(e) == 0);
 }
 
 bool tile_xcd_remap(const Grid &g) {

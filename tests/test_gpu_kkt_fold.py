@@ -158,3 +158,26 @@ def test_palm_folded_equals_unfolded(ny, nx, nt, K, ngpu, monkeypatch):
         a, b = getattr(got, f), getattr(ref, f)
         err = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
         assert err <= 1e-12, (f, err)
+
+
+@pytest.mark.parametrize("method", ["inPALM", "PALM", "acc-ADMM"])
+def test_nontemporal_streams_change_nothing(method, monkeypatch):
+    """The cone multipliers travel with the non-temporal cache policy (device_utils.h: ld_stream / st_stream): a hint to
+    the caches, no arithmetic -- every iterate and the KKT history are bit-identical with DOTSOCP_NT=0."""
+    rho0, rho1 = get_example_2d("example1", 70, 40)
+    res = []
+    for nt_on in ("1", "0"):
+        monkeypatch.setenv("DOTSOCP_NT", nt_on)
+        var, model = D.initialize(rho0, rho1, 17)
+        D.InitialScaling(var, model, True, None, dim=2)
+        o = OD.default_opts(dict(tol=0.0, maxit=40), method, False)
+        ctx = D.InPALMContext(var, o, model, method=method)
+        ctx.run(40)
+        hist, sigma = ctx.finish(download=True)
+        ctx.close()
+        res.append((var, hist, sigma))
+    (a, ha, sa), (b, hb, sb) = res
+    assert sa == sb
+    np.testing.assert_array_equal(ha["kkt"], hb["kkt"])
+    for f in ("phi", "q", "z", "alpha", "beta"):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)

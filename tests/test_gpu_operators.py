@@ -181,7 +181,9 @@ def test_oper_poisson(ny, nx, nt):
 def test_pipelined_dct_kernels_against_the_workgroup_wide_ones():
     """DOTSOCP_DCT_PIPE=0 (read once per process, hence the subprocesses) switches the persistent LDS-DMA kernels off; both
     families run the same butterflies on the same operands, so transforms and Poisson solves agree to rounding of the
-    few places where the order of operations differs (none in the transforms: identical bits expected there)."""
+    few places where the order of operations differs or where the compiler contracts a * b + c differently in the two
+    families (dct.hip is built with -ffp-contract=fast since round 3: the FFT has no operation-by-operation counterpart
+    in the reference)."""
     import os
     import subprocess
     import sys
@@ -202,6 +204,6 @@ def test_pipelined_dct_kernels_against_the_workgroup_wide_ones():
             assert r.returncode == 0, r.stderr[-2000:]
             with np.load(path) as z:
                 out[flag] = {k: z[k].copy() for k in z.files}
-    np.testing.assert_array_equal(out["1"]["f"], out["0"]["f"])
-    np.testing.assert_array_equal(out["1"]["i"], out["0"]["i"])
+    np.testing.assert_allclose(out["1"]["f"], out["0"]["f"], rtol=0, atol=1e-13 * np.abs(out["0"]["f"]).max())
+    np.testing.assert_allclose(out["1"]["i"], out["0"]["i"], rtol=0, atol=1e-13 * np.abs(out["0"]["i"]).max())
     np.testing.assert_allclose(out["1"]["p"], out["0"]["p"], rtol=0, atol=1e-13 * np.abs(out["0"]["p"]).max())
