@@ -1,7 +1,7 @@
 # round-3 evidence run (one MI355X): bench lines, rocprofv3 kernel tables (1024 and 1025 grids), PMC traffic of both grids,
 # rank share of the 8-way split, loop variants, end-to-end multilevel solves
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/ev3
+O=$GRAFT_REPO_ROOT/gpurun_out/ev4
 mkdir -p $O
 B="timeout -k 10 400 python bench.py"
 $B > $O/r03_bench_default.json 2> $O/err.txt; echo default done
