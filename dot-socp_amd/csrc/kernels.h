@@ -88,12 +88,18 @@ int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeo
 bool cone_split_enabled();
 
 // ---------------- acc.hip (acc-ADMM loop) ----------------
+struct KktWork;
 struct AccArgs {
     const double *q;                 // q^+ of this iteration (modes 0, 1)
     const double *z_in, *beta_in;    // current state
     const double *z0, *beta0;        // Halpern anchors (mode 1)
     double *z0_out, *beta0_out;      // mode 3: the anchors, written
     double bdiv;                     // mode 3: factor of the sigma update
+    // mode 0 on an iteration that ends with a KKT check (one slab; launch_acc_cone_kkt): the cell part of the KKT sums and the
+    // F*B*beta^+ terms of all edges are taken while z^+, beta^+ are in registers (k_kkt_cells<., true>'s sums and gather)
+    KktCoef kk;
+    const double *alpha_p, *weight;  // alpha^+ of the q-step, the weight field (or nullptr)
+    double *partials;
     double *z_out, *beta_out;        // mode 0: z^+, beta^+; mode 1: new state (buffers other than the inputs)
     double *q2, *sx, *sy;            // modes 1, 2: adjoint sums for the next q-step
     i64 TC;
@@ -106,6 +112,9 @@ struct AccCoef {
 // mode 0: multiplier + z-step, raw outputs; 1: + Halpern step + gather; 2: gather of (z + beta) only;
 // 3: mode 1 after a sigma update (beta, beta^+ divided by a.bdiv, anchors = x^+ stored)
 int launch_acc_cone(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, AccArgs a, hipStream_t st);
+// mode 0 + KKT sums: region 1 of the partial sums (cells, edges inside the tiles) and regions 2, 3 (edges on tile borders:
+// F*B*beta^+ only); a.q2 / sx / sy are scratch
+int launch_acc_cone_kkt(const Grid &g, const LoopCoef &c, const FusedGeom &fg, AccArgs a, const KktWork &w, hipStream_t st);
 // Halpern step right after a sigma update: x, x^+ divided by div, anchor = x^+ stored, x extrapolated with k = 0
 int launch_acc_restart(double *x, const double *xp, double *anchor, i64 n, const AccCoef &k, double div, hipStream_t st);
 // element-wise extrapolation of one state array (modes: see acc.hip)
@@ -236,6 +245,14 @@ int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double 
                const double *alpha, const double *z, const double *beta, const double *cvec,
                const double *weight, const KktHalo &halo, const KktWork &w, int parts, hipStream_t st,
                bool layer0 = false, double *resid = nullptr);
+// the node / q0-entry / edge sums that need no multiplier (parts 1, 16, 4, 8 of k_kkt without the F*B*beta terms): regions
+// 0, 4, 5, 6 of the partial sums -- what is left when the cone pass has taken the cell sums (launch_acc_cone_kkt)
+int launch_kkt_nodual(const Grid &g, const LoopCoef &c, const KktCoef &k, const double *phi, const double *q,
+                      const double *alpha, const double *cvec, const double *weight, const KktWork &w, hipStream_t st);
+// tile-border edges: F*B*beta terms from the raw partial sums in q2 / sx / sy (regions 2, 3)
+int launch_kkt_bnd_dual(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, const double *q,
+                        const double *alpha, const double *weight, const double *q2, const double *sx, const double *sy,
+                        const KktWork &w, hipStream_t st);
 // fused path: pending multiplier step (beta_in -> beta_out, distinct buffers) + the cell part of the sums
 // edges (one slab, after a q-step in its KKT variant): also the F*B*beta' sums of every edge and the momentum terms of
 // the edges on tile borders (a.q2 / a.sx / a.sy are scratch; q_new = q^{k+1})

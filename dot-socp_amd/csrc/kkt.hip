@@ -21,7 +21,9 @@ struct WBeta {
 
 // PART selects which entries a launch visits (1 node, 2 cell + its q0 entry, 4 bx edge, 8 by edge):
 // four lean launches keep the register count low and the occupancy high.
-template <bool WEIGHTED, int PART>
+// NODUAL (acc-ADMM's folded check: the cone pass has taken ||F*B*beta||^2 and ||F*B*beta + w.*alpha||^2 of every entry): the
+// F*B*beta terms are left out and beta is not read; PART 16 then is the q0 entries' share of the staggered sums.
+template <bool WEIGHTED, int PART, bool NODUAL = false>
 __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktCoef k, i64 chunk,
                                                          const double *__restrict__ phi, const double *__restrict__ q,
                                                          const double *__restrict__ alpha, const double *__restrict__ z,
@@ -60,9 +62,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
         S[S_APHI2] += tmp * tmp;
         const double r1 = tmp - wq;
         S[S_PRIM1] += r1 * r1;
-        S[S_FBBETA2] += q2b * q2b;
-        const double r2 = q2b + wa;
-        S[S_DUAL2] += r2 * r2;
+        if (!NODUAL) {
+            S[S_FBBETA2] += q2b * q2b;
+            const double r2 = q2b + wa;
+            S[S_DUAL2] += r2 * r2;
+        }
         S[S_QALPHA] += wq * av;
     };
     if (inb) {
@@ -138,12 +142,17 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
                 tmp += c.at * phi[node + g.plane];
                 edge_sums(node, tmp, c.s * (WB(9, node) - WB(0, node)));
             }
+            if ((PART & 16) && tl < g.ncl) {            // q0 entry alone (NODUAL)
+                double tmp = (-c.at) * phi[node];
+                tmp += c.at * phi[node + g.plane];
+                edge_sums(node, tmp, 0.0);
+            }
             // ---- bx edge (y, x+1/2, t) ----
             if ((PART & 4) && x < g.nx - 1) {
                 const i64 idx = bxo + y + g.py * x;
                 double tmp = (-c.ax) * phi[node];
                 tmp += c.ax * phi[node + g.py];
-                const double q2b = c.sf * gather_bx(g, WB, y, x, tl, halo.btail_bx);
+                const double q2b = NODUAL ? 0.0 : c.sf * gather_bx(g, WB, y, x, tl, halo.btail_bx);
                 edge_sums(idx, tmp, q2b);
                 const double rm = (rho_node(y, x, tl) + rho_node(y, x + 1, tl)) / 2.0;
                 const double rb = k.dsD * (rm * q[idx]);
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
                 const i64 idx = byo + y + g.pyb * x;
                 double tmp = (-c.ay) * phi[node];
                 tmp += c.ay * phi[node + 1];
-                const double q2b = c.sf * gather_by(g, WB, y, x, tl, halo.btail_by);
+                const double q2b = NODUAL ? 0.0 : c.sf * gather_by(g, WB, y, x, tl, halo.btail_by);
                 edge_sums(idx, tmp, q2b);
                 const double rm = (rho_node(y, x, tl) + rho_node(y + 1, x, tl)) / 2.0;
                 const double rb = k.dsD * (rm * q[idx]);
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(256) k_sumsq(const double *__restrict__ x, i64
 // Per edge: the momentum terms the q-step's KKT variant left out, and ||F*B*beta||^2, ||F*B*beta + w.*alpha||^2 from the raw
 // partial sums k_kkt_cells<., true> left in q2 / sx / sy.  alpha, q: the new iterates in memory.
 #define BND_TC 8
-template <bool WEIGHTED, int DIR>
+template <bool WEIGHTED, int DIR, bool NOMOM = false>
 __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, FusedGeom fg, const double *__restrict__ q,
                                                   const double *__restrict__ alpha, const double *__restrict__ weight,
                                                   const double *__restrict__ q2, const double *__restrict__ sx,
@@ -451,12 +460,14 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
         const i64 y = u, x = (i64)blockIdx.y * TILE_X + (TILE_X - 1);
         if (y < g.ny && x < g.nx - 1) {
             const i64 e = g.offBx + g.bxLayer * tl + y + g.py * x;
-            const double rm = (rho_node(y, x, tl) + rho_node(y, x + 1, tl)) / 2.0;
-            const double rb = k.dsD * (rm * q[e]);
-            const double m = k.kappa * (wgt(e) * alpha[e]);
-            const double d = m - rb;
-            sM += d * d;
-            sR += rb * rb;
+            if (!NOMOM) {
+                const double rm = (rho_node(y, x, tl) + rho_node(y, x + 1, tl)) / 2.0;
+                const double rb = k.dsD * (rm * q[e]);
+                const double m = k.kappa * (wgt(e) * alpha[e]);
+                const double d = m - rb;
+                sM += d * d;
+                sR += rb * rb;
+            }
             const double gb = c.sf * (q2[e] + sx[(tl * fg.nxblk + (x / TILE_X + 1)) * g.ny + y]);
             sF += gb * gb;
             const double r2 = gb + wgt(e) * alpha[e];
@@ -466,12 +477,14 @@ __global__ void __launch_bounds__(256) k_kkt_bnd(Grid g, LoopCoef c, KktCoef k, 
         const i64 x = u, y = (i64)blockIdx.y * 64 + 63;
         if (x < g.nx && y < g.ny - 1) {
             const i64 e = g.offBy + g.byLayer * tl + y + g.pyb * x;
-            const double rm = (rho_node(y, x, tl) + rho_node(y + 1, x, tl)) / 2.0;
-            const double rb = k.dsD * (rm * q[e]);
-            const double m = k.kappa * (wgt(e) * alpha[e]);
-            const double d = m - rb;
-            sM += d * d;
-            sR += rb * rb;
+            if (!NOMOM) {
+                const double rm = (rho_node(y, x, tl) + rho_node(y + 1, x, tl)) / 2.0;
+                const double rb = k.dsD * (rm * q[e]);
+                const double m = k.kappa * (wgt(e) * alpha[e]);
+                const double d = m - rb;
+                sM += d * d;
+                sR += rb * rb;
+            }
             const double gb = c.sf * (q2[e] + sy[(tl * g.nx + x) * fg.nyblk + (y / 64 + 1)]);
             sF += gb * gb;
             const double r2 = gb + wgt(e) * alpha[e];
@@ -586,6 +599,47 @@ int launch_kkt(const Grid &g, const LoopCoef &c, const KktCoef &k, const double 
     else { KKT_PART(false, 1, 0); KKT_PART(false, 2, 1); KKT_PART(false, 4, 2); KKT_PART(false, 8, 3); }
 #undef KKT_PART
     DS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_kkt_nodual(const Grid &g, const LoopCoef &c, const KktCoef &k, const double *phi, const double *q,
+                      const double *alpha, const double *cvec, const double *weight, const KktWork &w, hipStream_t st) {
+    dim3 grid;
+    i64 chunk;
+    kkt_geometry(g, grid, chunk);
+    const i64 region = kkt_region_blocks(g);
+    if (KKT_REGIONS * region > w.maxBlocks) {
+        set_error("kkt workspace too small");
+        return DOTSOCP_EINVAL;
+    }
+    const dim3 blk(TILE_Y, TILE_X);
+    const KktHalo halo{nullptr, nullptr, nullptr, nullptr};
+    const double *none = nullptr;
+#define KKT_ND(W, P, reg)                                                                                                 \
+    DS_KLAUNCH((k_kkt<W, P, true>), grid, blk, 0, st, g, c, k, chunk, phi, q, alpha, none, none, cvec, weight, halo, \
+               w.partials + (i64)(reg) * region * S_COUNT, (double *)nullptr)
+    if (weight) { KKT_ND(true, 1, 0); KKT_ND(true, 16, 4); KKT_ND(true, 4, 5); KKT_ND(true, 8, 6); }
+    else { KKT_ND(false, 1, 0); KKT_ND(false, 16, 4); KKT_ND(false, 4, 5); KKT_ND(false, 8, 6); }
+#undef KKT_ND
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_kkt_bnd_dual(const Grid &g, const LoopCoef &c, const KktCoef &k, const FusedGeom &fg, const double *q,
+                        const double *alpha, const double *weight, const double *q2, const double *sx, const double *sy,
+                        const KktWork &w, hipStream_t st) {
+    const i64 region = kkt_region_blocks(g);
+    for (int dir = 0; dir < 2; ++dir) {
+        const i64 len = dir == 0 ? g.ny : g.nx, lines = dir == 0 ? fg.nxblk : fg.nyblk;
+        if (len <= 0 || lines <= 0) continue;
+        dim3 gb((unsigned)((len + 255) / 256), (unsigned)lines, (unsigned)((g.ntl + BND_TC - 1) / BND_TC));
+        double *pb = w.partials + (2 + dir) * region * S_COUNT;
+#define BND(W, D) DS_KLAUNCH((k_kkt_bnd<W, D, true>), gb, dim3(256), 0, st, g, c, k, fg, q, alpha, weight, q2, sx, sy, pb)
+        if (weight) { if (dir == 0) BND(true, 0); else BND(true, 1); }
+        else { if (dir == 0) BND(false, 0); else BND(false, 1); }
+#undef BND
+        DS_HIP(hipGetLastError());
+    }
     return 0;
 }
 

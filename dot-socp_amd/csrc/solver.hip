@@ -1412,6 +1412,12 @@ int Solver::ensure_z() {
 int Solver::kkt_sums(double *S, bool folded) {
     DS_CHECK(ensure_halo());
     const KktCoef k = kkt_coef();
+    if (method == DOTSOCP_METHOD_ACCADMM && folded) {
+        // acc-ADMM, one slab: the cone pass of the iteration has taken the cell sums and the F*B*beta^+ terms of every entry
+        // (launch_acc_cone_kkt: regions 1-3, buffer cleared before it); left are the sums made of phi^+, q^+, alpha^+, c
+        FOR_SLABS(s) DS_CHECK(launch_kkt_nodual(s.g, lc, k, s.phi, s.q, s.alpha, s.c, s.weight, s.kw, s.st));
+        return reduce_sums(S);
+    }
     if (!folded) {
         DS_CHECK(flush_alpha());
         // the launches below write per-workgroup partial sums into four regions; grids of different
@@ -1673,7 +1679,7 @@ int Solver::kkt_block(bool adjustSigmaYes, bool timed_out, bool *brk, bool folde
         double factor;
         adjust_lagrangian_param(sigma, resiPri / resiDual, factor);
         if (factor != 1.0) {
-            if (folded && rhs_valid) DS_CHECK(sigma_scale_folded(factor));
+            if (folded && rhs_valid && method != DOTSOCP_METHOD_ACCADMM) DS_CHECK(sigma_scale_folded(factor));
             else DS_CHECK(scale_state(1.0, factor, 1.0, true));
             if (method == DOTSOCP_METHOD_ACCADMM) DS_CHECK(acc_on_sigma_factor(factor));
         }

@@ -184,6 +184,9 @@ int Solver::acc_step(bool *brk) {
     // an iteration with a KKT check: x^+ is stored for the block; afterwards z and beta are extrapolated by a second cone pass
     // that recomputes x^+ from the (untouched) state, applies the block's sigma factor and emits the next gather
     const bool post = acc_halpern && kkt_due && acc_post;
+    // one slab: the KKT sums that need z^+ and beta^+ are taken by the cone pass itself, which then runs AFTER the phi-step
+    // (it does not depend on phi^+, the sums do): nothing of the block reads z^+ or beta^+ from memory again
+    const bool kfold = kkt_due && kkt_fold && !multi();
 
     // ---- step q (:227-232) ----
     if (!acc_gather_valid) {
@@ -227,7 +230,11 @@ int Solver::acc_step(bool *brk) {
     }
 
     // ---- multipliers + step z (:234-239,246-249); the cone pass does not need phi^+ ----
-    prof_begin(PH_ACC_CONE);
+    auto cone_pass = [&]() -> int {
+    prof_begin(kfold ? PH_FUSED_A : PH_ACC_CONE);      // the KKT flavour is timed apart (bench.py prices acc_cone as mode 1)
+    if (kfold) {
+        FOR_SLABS(s) DS_HIP(ds_memset_async(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
+    }
     FOR_SLABS(s) {
         AccArgs a{};
         a.q = s.q_old;
@@ -238,9 +245,19 @@ int Solver::acc_step(bool *brk) {
             a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;
             a.c1 = kc.c1; a.c2 = kc.c2; a.om_rho = kc.om_rho; a.rho = kc.rho;
         }
-        DS_CHECK(launch_acc_cone(fold ? 1 : 0, s.g, lc, s.fg, a, s.st));
+        if (kfold) {
+            a.kk = kkt_coef();
+            a.alpha_p = s.alpha_p; a.weight = s.weight;
+            a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;          // scratch: this iteration's q-step has consumed the gather
+            DS_CHECK(launch_acc_cone_kkt(s.g, lc, s.fg, a, s.kw, s.st));
+        } else {
+            DS_CHECK(launch_acc_cone(fold ? 1 : 0, s.g, lc, s.fg, a, s.st));
+        }
     }
-    prof_end(PH_ACC_CONE);
+    prof_end(kfold ? PH_FUSED_A : PH_ACC_CONE);
+    return 0;
+    };
+    if (!kfold) DS_CHECK(cone_pass());
 
     // ---- step phi (:241-244) ----
     prof_begin(PH_POISSON);
@@ -249,6 +266,7 @@ int Solver::acc_step(bool *brk) {
     for (auto &s : slabs) std::swap(s.phi, s.phi_p);
     DS_CHECK(rc);
     prof_end(PH_POISSON);
+    if (kfold) DS_CHECK(cone_pass());
 
     // ---- KKT (:251-367) at x^+ ----
     if (kkt_due) {
@@ -260,7 +278,7 @@ int Solver::acc_step(bool *brk) {
         acc_swap_state();
         acc_light = post;
         acc_factor = 1.0;
-        rc = kkt_block(adjustSigmaYes, timed_out, brk);
+        rc = kkt_block(adjustSigmaYes, timed_out, brk, kfold);
         acc_light = false;
         DS_CHECK(rc);
         if (*brk) return 0;                                // :322-325: the outputs are x^+ (pointers stay swapped)

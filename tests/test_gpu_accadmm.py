@@ -166,3 +166,42 @@ def test_post_kkt_cone_pass_changes_nothing(case, monkeypatch):
     np.testing.assert_array_equal(ha["kkt"], hb["kkt"])
     for f in FIELDS:
         np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
+
+
+@pytest.mark.parametrize("case", ["halpern", "theta3", "weighted", "checkstep", "cut_tiles"])
+def test_folded_kkt_equals_unfolded(case, monkeypatch):
+    """One slab: on an iteration that ends with a KKT check the cone pass runs after the phi-step and takes the cell sums
+    and the F*B*beta^+ terms of every entry while z^+, beta^+ are in registers (k_acc_cone<RAW, ., KKT>, k_kkt_bnd for the
+    tile borders), and what is left -- the sums made of phi^+, q^+, alpha^+, c -- comes from k_kkt's lean parts without a
+    read of beta.  Against the unfolded block (DOTSOCP_KKT_FOLD=0: four launches that read z^+, beta^+ from memory):
+    the same sums in another order of summation -- KKT histories to 1e-9 relative, iterates to 1e-11."""
+    ny, nx, nt, K = 32, 32, 16, 70
+    opts, weight = dict(tol=0.0, maxit=K), None
+    if case == "theta3":
+        opts.update(theta=3.0, restart=8, maxit=40)
+    if case == "checkstep":
+        opts.update(ifCheckStepByStep=True, maxit=20)
+    if case == "cut_tiles":
+        ny, nx, nt = 70, 41, 11
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    if case == "weighted":
+        barrier = gene_barrier_of_circle_pillar()
+        weight = get_weight_by_barrier(ny, nx, nt, barrier)
+        rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    res = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("DOTSOCP_KKT_FOLD", fold)
+        var, model = D.initialize(rho0, rho1, nt)
+        if weight is not None:
+            model.weight = np.asarray(weight, dtype=np.float64)
+        oo = OD.default_opts(opts, "acc-ADMM", weight is not None)
+        D.InitialScaling(var, model, oo["scaling"], None, dim=2, weighted=weight is not None)
+        solve = D.solver_wsocp_accADMM if weight is not None else D.solver_socp_accADMM
+        hist, sigma = solve(var, oo, model)
+        res.append((var, hist, sigma))
+    (a, ha, sa), (b, hb, sb) = res
+    assert abs(sa - sb) <= 1e-13 * abs(sb)
+    np.testing.assert_array_equal(ha["iter"], hb["iter"])
+    np.testing.assert_allclose(ha["kkt"], hb["kkt"], rtol=1e-9, atol=1e-14)
+    errs = {f: _relerr(getattr(a, f), getattr(b, f)) for f in FIELDS}
+    assert max(errs.values()) <= (1e-9 if weight is not None else 1e-11), errs
