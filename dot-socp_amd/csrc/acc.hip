@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                 for (int j = 0; j < 10; ++j) v[j] = v[j] - bp[j];
                 proj_row<10>(v);                      // v = z^+
                 if (MODE == ACC_RAW) {
-                    if (own && inb) {
+                    if (own && inb && !(KKT && a.nostore)) {
 #pragma unroll
                         for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, bp[j]);
 #pragma unroll

@@ -100,6 +100,7 @@ struct AccArgs {
     KktCoef kk;
     const double *alpha_p, *weight;  // alpha^+ of the q-step, the weight field (or nullptr)
     double *partials;
+    int nostore;                     // ... and z^+, beta^+ are not written (the pass after the block recomputes them)
     double *z_out, *beta_out;        // mode 0: z^+, beta^+; mode 1: new state (buffers other than the inputs)
     double *q2, *sx, *sy;            // modes 1, 2: adjoint sums for the next q-step
     i64 TC;

@@ -248,6 +248,7 @@ int Solver::acc_step(bool *brk) {
         if (kfold) {
             a.kk = kkt_coef();
             a.alpha_p = s.alpha_p; a.weight = s.weight;
+            a.nostore = post ? 1 : 0;       // x^+ is recomputed by the pass after the block; stored only for a stop (below)
             a.q2 = s.q2; a.sx = s.sx; a.sy = s.sy;          // scratch: this iteration's q-step has consumed the gather
             DS_CHECK(launch_acc_cone_kkt(s.g, lc, s.fg, a, s.kw, s.st));
         } else {
@@ -281,7 +282,20 @@ int Solver::acc_step(bool *brk) {
         rc = kkt_block(adjustSigmaYes, timed_out, brk, kfold);
         acc_light = false;
         DS_CHECK(rc);
-        if (*brk) return 0;                                // :322-325: the outputs are x^+ (pointers stay swapped)
+        if (*brk) {                                        // :322-325: the outputs are x^+ (pointers stay swapped)
+            if (kfold && post) {                           // ... whose z^+, beta^+ the folded cone pass did not store
+                acc_swap_state();
+                FOR_SLABS(s) {
+                    AccArgs a{};
+                    a.q = s.q_old;
+                    a.z_in = s.z; a.beta_in = s.beta;
+                    a.z_out = s.z_p; a.beta_out = s.beta2;
+                    DS_CHECK(launch_acc_cone(0, s.g, lc, s.fg, a, s.st));
+                }
+                acc_swap_state();
+            }
+            return 0;
+        }
         acc_swap_state();
     }
 
