@@ -390,7 +390,7 @@ __device__ __forceinline__ double2 dct_post(const double2 *__restrict__ r, int k
 // ---------------------------------------------------------------------------------------------
 template <bool INVERSE>
 __global__ void __launch_bounds__(DCT_THREADS) k_dct_axis0(const double *__restrict__ src, double *__restrict__ dst,
-                                                            i64 nLines, int lg, int lrw,
+                                                            i64 nLines, i64 ls /* doubles between lines */, int lg, int lrw,
                                                             const double2 *__restrict__ tw,
                                                             const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_axis0(const double *__restr
             const i64 La = 2 * (pair0 + rr);
             A[u] = make_double2(0.0, 0.0);
             B[u] = A[u];
-            if (b < total && La < nLines) A[u] = *(const double2 *)(src + La * n + 2 * j);
-            if (b < total && La + 1 < nLines) B[u] = *(const double2 *)(src + (La + 1) * n + 2 * j);
+            if (b < total && La < nLines) A[u] = *(const double2 *)(src + La * ls + 2 * j);
+            if (b < total && La + 1 < nLines) B[u] = *(const double2 *)(src + (La + 1) * ls + 2 * j);
         }
 #pragma unroll
         for (int u = 0; u < DCT_BATCH; ++u) {
@@ -448,8 +448,8 @@ __global__ void __launch_bounds__(DCT_THREADS) k_dct_axis0(const double *__restr
             A = make_double2(v0.x, v1.x);                      // x[2j] = v[j], x[2j+1] = v[n-1-j]
             B = make_double2(v0.y, v1.y);
         }
-        if (La < nLines) *(double2 *)(dst + La * n + 2 * j) = A;
-        if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * n + 2 * j) = B;
+        if (La < nLines) *(double2 *)(dst + La * ls + 2 * j) = A;
+        if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * ls + 2 * j) = B;
     }
     (void)rw;
 }
@@ -671,7 +671,7 @@ __device__ __forceinline__ void idct_combine_wg(double2 *rows, int lrows, int lg
 // Axis 0, workgroup-wide: the workgroup stages 2^lrows complex rows (pairs of consecutive lines).
 template <bool INVERSE>
 __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double *__restrict__ src,
-                                                                     double *__restrict__ dst, i64 nLines, int lg,
+                                                                     double *__restrict__ dst, i64 nLines, i64 ls, int lg,
                                                                      int lrows, const double2 *__restrict__ tw,
                                                                      const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
@@ -689,8 +689,8 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
             const i64 La = 2 * (pair0 + rr);
             A[u] = make_double2(0.0, 0.0);
             B[u] = A[u];
-            if (b < total && La < nLines) A[u] = *(const double2 *)(src + La * n + 2 * j);
-            if (b < total && La + 1 < nLines) B[u] = *(const double2 *)(src + (La + 1) * n + 2 * j);
+            if (b < total && La < nLines) A[u] = *(const double2 *)(src + La * ls + 2 * j);
+            if (b < total && La + 1 < nLines) B[u] = *(const double2 *)(src + (La + 1) * ls + 2 * j);
         }
 #pragma unroll
         for (int u = 0; u < DCT_BATCH; ++u) {
@@ -724,8 +724,8 @@ __global__ void __launch_bounds__(DCT_WG_THREADS, 4) k_dct_axis0_wg(const double
             A = make_double2(v0.x, v1.x);
             B = make_double2(v0.y, v1.y);
         }
-        if (La < nLines) *(double2 *)(dst + La * n + 2 * j) = A;
-        if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * n + 2 * j) = B;
+        if (La < nLines) *(double2 *)(dst + La * ls + 2 * j) = A;
+        if (La + 1 < nLines) *(double2 *)(dst + (La + 1) * ls + 2 * j) = B;
     }
 }
 
@@ -843,10 +843,13 @@ __device__ __forceinline__ void fft_rows_pipe(double2 *rows, int t, TW tw) {
 
 template <bool INVERSE, int LG>
 __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *__restrict__ src, double *__restrict__ dst,
-                                                                  int nTiles, const double2 *__restrict__ tw,
+                                                                  int nTiles, i64 ls /* doubles between lines */,
+                                                                  const double2 *__restrict__ tw,
                                                                   const double2 *__restrict__ ww) {
     extern __shared__ double2 lds[];
     constexpr int n = 1 << LG, lh = LG - 1;
+    constexpr int LPT = (2 << PIPE_LG_CPLX) / n;      // lines per tile
+    constexpr int PPL = n / 128;                      // 1-KB DMA pieces per line
     constexpr int RS = n + 1;                         // odd row stride: rows start on different banks
     constexpr int lrows = PIPE_LG_CPLX - LG;          // 2^lrows rows (pairs of lines) per tile
     constexpr int BUF = RS << lrows;                  // complex elements per buffer
@@ -862,11 +865,15 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
     typename std::conditional<BIG, WwHalf, const double2 *>::type wwA;
     if constexpr (BIG) { twA = TwQuarter{twS, n >> 2}; wwA = WwHalf{wwS, n >> 1}; } else { twA = twS; wwA = wwS; }
     const unsigned ldsBase = (unsigned)(uintptr_t)lds;
+    // the lines of a tile land back to back in LDS (n doubles apart) whatever their distance in memory
     auto dma = [&](int tile, int b) {
-        const char *g = (const char *)(src + ((i64)tile << (PIPE_LG_CPLX + 1))) + (wave * PIPE_ND) * 1024 + lane * 16;
+        const char *g = (const char *)(src + (i64)tile * LPT * ls) + lane * 16;
         const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16) + (unsigned)(wave * PIPE_ND) * 1024u;
 #pragma unroll
-        for (int i = 0; i < PIPE_ND; ++i) glds16(g + i * 1024, l0 + (unsigned)i * 1024u);
+        for (int i = 0; i < PIPE_ND; ++i) {
+            const int piece = wave * PIPE_ND + i;
+            glds16(g + (i64)(piece / PPL) * (ls * 8) + (piece % PPL) * 1024, l0 + (unsigned)i * 1024u);
+        }
     };
     int tile = blockIdx.x;
     const int stride = gridDim.x;
@@ -910,7 +917,7 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
         lds_barrier();
         if (INVERSE) idct_combine_wg<true>(buf, lrows, LG, RS, tid, PIPE_THREADS, wwA);
         fft_rows_pipe<LG, lrows, PIPE_THREADS, RS>(buf, tid, twA);
-        double *out = dst + ((i64)tile << (PIPE_LG_CPLX + 1));
+        double *out = dst + (i64)tile * LPT * ls;
 #pragma unroll
         for (int u = 0; u < PIPE_IT; ++u) {
             const int rr = item_row(u), j0 = item_j(u);
@@ -925,8 +932,8 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_axis0_pipe(const double *_
                 Av = make_double2(v0.x, v1.x);
                 Bv = make_double2(v0.y, v1.y);
             }
-            *(double2 *)(out + (2 * rr) * n + 2 * j0) = Av;
-            *(double2 *)(out + (2 * rr + 1) * n + 2 * j0) = Bv;
+            *(double2 *)(out + (2 * rr) * ls + 2 * j0) = Av;
+            *(double2 *)(out + (2 * rr + 1) * ls + 2 * j0) = Bv;
         }
         // the next tile has landed when only this tile's stores are outstanding; one barrier then says both "every wave's
         // pieces of the next tile are in LDS" and "this buffer is drained"
@@ -974,7 +981,7 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
             const int c = wave * PIPE_ND + i;                         // piece: slots 64 c .. 64 c + 63
             const int p = padi(((c << 6) + lane) >> lrows);          // position held by this lane's slot
             const int k = (MODE == 1) ? p : ((p < (n >> 1)) ? 2 * p : 2 * (n - 1 - p) + 1);
-            glds16(g0 + (i64)k * map.nin, l0 + (unsigned)c * 1024u);
+            glds16(g0 + (i64)k * map.es, l0 + (unsigned)c * 1024u);
         }
     };
     // tile order: workgroup w runs on XCD w % 8; the tiles 2p and 2p + 1 (n = 2048, tiles 32 bytes wide: 4p .. 4p + 3) that
@@ -998,8 +1005,8 @@ __global__ void __launch_bounds__(PIPE_THREADS) k_dct_strided_pipe(const double 
             // item u of this thread: pair r0, k = k0 + u * (threads / NP)
             const int r0 = tid & (NP - 1), k0 = tid >> lrows;
             const double2 *rr = buf + r0;
-            double *o = dst + tile_base(tile) + 2 * r0 + (i64)k0 * map.nin;
-            const i64 ostep = (i64)(PIPE_THREADS >> lrows) * map.nin;
+            double *o = dst + tile_base(tile) + 2 * r0 + (i64)k0 * map.es;
+            const i64 ostep = (i64)(PIPE_THREADS >> lrows) * map.es;
 #pragma unroll
             for (int u = 0; u < 2 * PIPE_IT; ++u) {
                 const int k = k0 + u * (PIPE_THREADS >> lrows);
@@ -1052,14 +1059,14 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
     // slot (padi(p) << lrows) + r holds position p of pair r; the forward transform is decimation-in-time, so position p
     // is element makhoul^-1(bitrev(p)) of the line
     auto dma = [&](int tile, int b) {
-        const double *g0 = src + ((i64)tile << (lrows + 1)) + 2 * (lane & (NP - 1));
+        const double *g0 = src + map.base((i64)tile << (lrows + 1)) + 2 * (lane & (NP - 1));   // pitched rows: a tile lies in one row
         const unsigned l0 = ldsBase + (unsigned)b * (unsigned)(BUF * 16);
 #pragma unroll
         for (int i = 0; i < TS_ND; ++i) {
             const int c = wave * TS_ND + i;
             const int q = bitrev(padi(((c << 6) + lane) >> lrows), LG);
             const int k = (q < (n >> 1)) ? 2 * q : 2 * (n - 1 - q) + 1;
-            glds16(g0 + (i64)k * map.nin, l0 + (unsigned)c * 1024u);
+            glds16(g0 + (i64)k * map.es, l0 + (unsigned)c * 1024u);
         }
     };
     int tile = blockIdx.x;
@@ -1129,8 +1136,8 @@ __global__ void __launch_bounds__(TS_THREADS) k_dct_tsolve_pipe(const double *__
         {
             const int r0 = tid & (NP - 1), k0 = tid >> lrows;
             const double2 *rr = buf + r0;
-            double *o = dst + ((i64)tile << (lrows + 1)) + 2 * r0 + (i64)k0 * map.nin;
-            const i64 ostep = (i64)(TS_THREADS >> lrows) * map.nin;
+            double *o = dst + map.base((i64)tile << (lrows + 1)) + 2 * r0 + (i64)k0 * map.es;
+            const i64 ostep = (i64)(TS_THREADS >> lrows) * map.es;
 #pragma unroll
             for (int u = 0; u < 2 * TS_IT; ++u) {
                 const int k = k0 + u * (TS_THREADS >> lrows);
@@ -1604,7 +1611,9 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
     // one 16-byte access carries both lines of a pair when consecutive lines are adjacent, even-aligned doubles
     const bool vec = (map.nin % 2 == 0) && (map.outerStride % 2 == 0) && (map.es % 2 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
     // fused t-axis solve, pipelined: eigenvalue tables in LDS, a tile = consecutive columns of one x
-    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 5 && lg <= 10 && map.outerStride == 0 && map.es == map.nin) {
+    // (rows of whole layers may be pitched: map.nin = ny lines per row, rows map.outerStride apart, time nodes map.es apart)
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode == 2 && lg >= 5 && lg <= 10 &&
+        ((map.outerStride == 0 && map.es == map.nin) || (map.nin == sa.ny && sa.line0 == 0))) {
         const i64 tileLines = ((i64)2 << TS_LG_CPLX) / n;
         const i64 nxv = sa.ny > 0 ? sa.nplane / sa.ny : 0;
         const size_t ldsPipe = (((size_t)2 << TS_LG_CPLX) + (size_t)(n >> 1) + (size_t)n) * sizeof(double2) +
@@ -1631,7 +1640,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
         }
     }
     // pipelined persistent kernel (see k_dct_axis0_pipe): whole tiles of 4096 complex values, the chip filled twice over
-    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 11 && map.es == map.nin) {
+    if (dct_pipe_enabled() && dct_wg_enabled() && vec && mode != 2 && lg >= 7 && lg <= 11) {
         const i64 tileLines = ((i64)2 << PIPE_LG_CPLX) / n;
         const int G = device_cus() & ~31;
         if (map.nin % tileLines == 0 && map.nLines % tileLines == 0 && G >= 32 && map.nLines / tileLines >= 2 * (i64)G &&
@@ -1771,8 +1780,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
         else if (axis == 1) { map.nin = n0; map.outerStride = n0 * n1; map.es = n0; }
         else { map.nin = n0 * n1; map.outerStride = 0; map.es = n0 * n1; }
     } else {
-        // (a power-of-two n0 is never pitched; power-of-two n1 / n2 beside a pitched n0 take the kernels that honour map.es)
-        if (p->log2n > 0 && axis == 0) { set_error("power-of-two transforms along y run on unpitched rows"); return DOTSOCP_EINVAL; }
+        // (power-of-two lengths: the axis-0 kernels take the line distance as an argument, the strided ones honour map.es)
         if (axis == 0) { map.nin = 1; map.outerStride = P0; map.es = 1; }
         else if (axis == 1) { map.nin = n0; map.outerStride = P0 * n1; map.es = P0; }
         else { map.nin = n0; map.outerStride = P0; map.es = P0 * n1; }
@@ -1820,7 +1828,7 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
                 const size_t ldsPipe = (2 * (rs << (PIPE_LG_CPLX - lg)) + ntab) * sizeof(double2);
 #define PIPE_LAUNCH(INV, LGV)                                                                                        \
     DS_KLAUNCH((k_dct_axis0_pipe<INV, LGV>), dim3((unsigned)ncu), dim3(PIPE_THREADS), ldsPipe, st, src, dst, \
-                       (int)nTiles, p->tw, p->ww)
+                       (int)nTiles, map.outerStride, p->tw, p->ww)
                 if (inverse) {
                     if (lg == 11) PIPE_LAUNCH(true, 11); else if (lg == 10) PIPE_LAUNCH(true, 10); else if (lg == 9) PIPE_LAUNCH(true, 9);
                     else if (lg == 8) PIPE_LAUNCH(true, 8); else PIPE_LAUNCH(true, 7);
@@ -1839,19 +1847,19 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             const unsigned wblocks = (unsigned)((((map.nLines + 1) / 2) + ((i64)1 << lrows) - 1) >> lrows);
             if (inverse)
                 DS_KLAUNCH(k_dct_axis0_wg<true>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
-                                   lg, lrows, p->tw, p->ww);
+                                   map.outerStride, lg, lrows, p->tw, p->ww);
             else
                 DS_KLAUNCH(k_dct_axis0_wg<false>, dim3(wblocks), dim3(DCT_WG_THREADS), lds, st, src, dst, map.nLines,
-                                   lg, lrows, p->tw, p->ww);
+                                   map.outerStride, lg, lrows, p->tw, p->ww);
             DS_HIP(hipGetLastError());
             return 0;
         }
         if (inverse)
-            DS_KLAUNCH(k_dct_axis0<true>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
-                               p->tw, p->ww);
+            DS_KLAUNCH(k_dct_axis0<true>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, map.outerStride,
+                               lg, lrw, p->tw, p->ww);
         else
-            DS_KLAUNCH(k_dct_axis0<false>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, lg, lrw,
-                               p->tw, p->ww);
+            DS_KLAUNCH(k_dct_axis0<false>, dim3(blocks), dim3(DCT_THREADS), lds, st, src, dst, map.nLines, map.outerStride,
+                               lg, lrw, p->tw, p->ww);
     } else {
         // DOTSOCP_PFA=0: the dense product also for the lengths that have a prime-factor transform
         static const bool pfa_on = !(getenv("DOTSOCP_PFA") && atoi(getenv("DOTSOCP_PFA")) == 0);

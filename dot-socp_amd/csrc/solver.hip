@@ -294,7 +294,15 @@ int Solver::ensure_alloc() {
 // (y, x) columns of a layer linearly).  DOTSOCP_PITCH=0: never.
 i64 Solver::row_pitch() const {
     static const bool on = !(getenv("DOTSOCP_PITCH") && atoi(getenv("DOTSOCP_PITCH")) == 0);
-    if (!on || world != 1 || ny <= 16 || ny % 16 == 0) return ny;
+    if (!on || world != 1 || ny <= 16) return ny;
+    if (ny % 16 == 0) {
+        // Rows whose length in bytes is a multiple of 2 KB: the x lines of the Poisson solve (one 64-byte piece per row, rows a
+        // power of two apart) keep hitting the same DRAM banks -- with rows 128 bytes longer the x passes of the pipelined DCT
+        // kernels take 0.41 / 0.47 instead of 0.50 / 0.52 ms at 1024 x 1024 x 128 (rocprofv3, same box).  DOTSOCP_PITCH2=0: off.
+        const char *e = getenv("DOTSOCP_PITCH2");
+        const bool on2 = !(e && atoi(e) == 0);
+        return (on2 && ny >= 512 && ny % 256 == 0) ? ny + 16 : ny;
+    }
     return (ny + 15) / 16 * 16;
 }
 

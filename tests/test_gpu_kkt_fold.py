@@ -181,3 +181,30 @@ def test_nontemporal_streams_change_nothing(method, monkeypatch):
     np.testing.assert_array_equal(ha["kkt"], hb["kkt"])
     for f in ("phi", "q", "z", "alpha", "beta"):
         np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
+
+
+@pytest.mark.parametrize("ny,nx,nt,method", [(512, 64, 16, "inPALM"), (512, 40, 9, "inPALM"), (768, 32, 8, "inPALM"),
+                                              (512, 64, 16, "PALM"), (512, 64, 16, "acc-ADMM")])
+def test_longer_rows_for_power_of_two_heights_change_nothing(ny, nx, nt, method, monkeypatch):
+    """Single-slab contexts store rows of 512, 768, 1024, ... doubles 16 doubles longer (Solver::row_pitch: rows a multiple of
+    2 KB apart keep the x lines of the Poisson solve on the same DRAM banks).  Only addresses change: the same lines share
+    a complex transform, every kernel sums in the same order -- bit-identical with DOTSOCP_PITCH2=0.  Covers the pipelined
+    DCT kernels on pitched rows (y: line distance as an argument, x / t: LineMap with es != nin), the generic ones for
+    the short axes, PALM's and acc-ADMM's kernels."""
+    rho0, rho1 = get_example_2d("example1", ny, nx)
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("DOTSOCP_PITCH2", on)
+        var, model = D.initialize(rho0, rho1, nt)
+        D.InitialScaling(var, model, True, None, dim=2)
+        o = OD.default_opts(dict(tol=0.0, maxit=12), method, False)
+        ctx = D.InPALMContext(var, o, model, method=method)
+        ctx.run(12)
+        hist, sigma = ctx.finish(download=True)
+        ctx.close()
+        res.append((var, hist, sigma))
+    (a, ha, sa), (b, hb, sb) = res
+    assert sa == sb
+    np.testing.assert_array_equal(ha["kkt"], hb["kkt"])
+    for f in ("phi", "q", "z", "alpha", "beta"):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
