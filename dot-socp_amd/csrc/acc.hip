@@ -63,9 +63,9 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
             const i64 i = yc + g.py * (xc + g.nx * tl);
             double b[10], zz[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nz + i);
+            for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nc + i);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) zz[j] = ld_stream<NT>(a.z_in + j * g.Nz + i);
+            for (int j = 0; j < 10; ++j) zz[j] = ld_stream<NT>(a.z_in + j * g.Nc + i);
             if (MODE == ACC_GATHER) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) w[j] = zz[j] + b[j];
@@ -91,9 +91,9 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                 if (MODE == ACC_RAW) {
                     if (own && inb && !(KKT && a.nostore)) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, bp[j]);
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nc + i, bp[j]);
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nz + i, v[j]);
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nc + i, v[j]);
                     }
                     if (KKT) {
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                     double zn[10], bn[10];
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
-                        const double z0 = (MODE == ACC_RESTART) ? v[j] : ld_stream<NT>(a.z0 + j * g.Nz + i);
+                        const double z0 = (MODE == ACC_RESTART) ? v[j] : ld_stream<NT>(a.z0 + j * g.Nc + i);
                         double t = a.om_rho * zz[j];
                         t = t + a.rho * v[j];
                         zn[j] = a.c1 * z0 + a.c2 * t;
@@ -166,21 +166,21 @@ __global__ void __launch_bounds__(64 * XB) k_acc_cone(Grid g, LoopCoef c, AccArg
                     }
 #pragma unroll
                     for (int j = 0; j < 10; ++j) {
-                        const double b0 = (MODE == ACC_RESTART) ? bp[j] : ld_stream<NT>(a.beta0 + j * g.Nz + i);
+                        const double b0 = (MODE == ACC_RESTART) ? bp[j] : ld_stream<NT>(a.beta0 + j * g.Nc + i);
                         double t = a.om_rho * b[j];
                         t = t + a.rho * bp[j];
                         bn[j] = a.c1 * b0 + a.c2 * t;
                     }
                     if (own && inb) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nz + i, zn[j]);
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nc + i, zn[j]);
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, bn[j]);
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nc + i, bn[j]);
                         if (MODE == ACC_RESTART) {
 #pragma unroll
-                            for (int j = 0; j < 10; ++j) st_stream<NT>(a.z0_out + j * g.Nz + i, v[j]);
+                            for (int j = 0; j < 10; ++j) st_stream<NT>(a.z0_out + j * g.Nc + i, v[j]);
 #pragma unroll
-                            for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta0_out + j * g.Nz + i, bp[j]);
+                            for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta0_out + j * g.Nc + i, bp[j]);
                         }
                     }
 #pragma unroll

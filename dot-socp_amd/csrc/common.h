@@ -64,10 +64,12 @@ struct Grid {
     i64 plane;             // py*nx
     i64 bxLayer, byLayer;  // py*(nx-1), pyb*nx
     i64 Nphi, Nz;          // owned nodes / cells
+    i64 Nc;                // doubles between the ten columns of a cone array (z, beta): Nz, or Nz + a pad that keeps the columns
+                           // off each other's DRAM banks (Nz * 8 bytes is a multiple of every power of two in sight)
     i64 offBx, offBy, NqAlloc;  // local q layout: [q0 | bx (ntl+halo layers) | by (ntl+halo layers)]
     i64 NphiAlloc;         // plane*(ntl+halo)
 
-    __host__ __device__ void set(i64 ny_, i64 nx_, i64 nt_, i64 t0_, i64 ntl_, i64 py_ = 0) {
+    __host__ __device__ void set(i64 ny_, i64 nx_, i64 nt_, i64 t0_, i64 ntl_, i64 py_ = 0, i64 cpad_ = 0) {
         ny = ny_; nx = nx_; nt = nt_; t0 = t0_; ntl = ntl_;
         py = (py_ > ny_) ? py_ : ny_;
         pyb = (py > ny) ? py : ny - 1;
@@ -80,6 +82,7 @@ struct Grid {
         byLayer = pyb * nx;
         Nphi = plane * ntl;
         Nz = plane * ncl;
+        Nc = Nz + (cpad_ > 0 ? cpad_ : 0);
         offBx = Nz;
         offBy = offBx + bxLayer * (ntl + halo);
         NqAlloc = offBy + byLayer * (ntl + halo);

@@ -78,16 +78,16 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd(Grid g, double *__restri
     const i64 i = y + g.py * (x + g.nx * tl);
     const double q0 = q[i];
     z[i] = dF - s * q0;
-    z[9 * g.Nz + i] = dF + s * q0;
+    z[9 * g.Nc + i] = dF + s * q0;
     const double *bx = q + g.offBx;
     const double *by = q + g.offBy;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         const i64 tt = tl + dt;
-        if (x >= 1) z[(1 + 2 * dt) * g.Nz + i] = sf * bx[g.bxLayer * tt + y + g.py * (x - 1)];
-        if (x <= g.nx - 2) z[(2 + 2 * dt) * g.Nz + i] = sf * bx[g.bxLayer * tt + y + g.py * x];
-        if (y >= 1) z[(5 + 2 * dt) * g.Nz + i] = sf * by[g.byLayer * tt + (y - 1) + g.pyb * x];
-        if (y <= g.ny - 2) z[(6 + 2 * dt) * g.Nz + i] = sf * by[g.byLayer * tt + y + g.pyb * x];
+        if (x >= 1) z[(1 + 2 * dt) * g.Nc + i] = sf * bx[g.bxLayer * tt + y + g.py * (x - 1)];
+        if (x <= g.nx - 2) z[(2 + 2 * dt) * g.Nc + i] = sf * bx[g.bxLayer * tt + y + g.py * x];
+        if (y >= 1) z[(5 + 2 * dt) * g.Nc + i] = sf * by[g.byLayer * tt + (y - 1) + g.pyb * x];
+        if (y <= g.ny - 2) z[(6 + 2 * dt) * g.Nc + i] = sf * by[g.byLayer * tt + y + g.pyb * x];
     }
 }
 
@@ -106,11 +106,11 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_bfd_conj(Grid g, double *__r
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
-    WPlain W{w, g.Nz};
+    WPlain W{w, g.Nc};
     if (seg == 0) {
         if (y >= g.ny || x >= g.nx) return;
         const i64 i = y + g.py * (x + g.nx * tl);
-        q[i] = s * (w[9 * g.Nz + i] - w[i]);
+        q[i] = s * (w[9 * g.Nc + i] - w[i]);
     } else if (seg == 1) {
         if (y >= g.ny || x >= g.nx - 1) return;
         q[g.offBx + g.bxLayer * tl + y + g.py * x] = sf * gather_bx(g, W, y, x, tl, tail_bx);
@@ -161,15 +161,15 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_cone_march(Grid g, LoopCoef 
         build_z2(v, q[i], cur, nxt, c.s, c.dF);
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = v[j] - betain[j * g.Nz + i];
+            for (int j = 0; j < 10; ++j) v[j] = v[j] - betain[j * g.Nc + i];
             proj_row<10>(v);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) zout[j * g.Nz + i] = v[j];
+            for (int j = 0; j < 10; ++j) zout[j * g.Nc + i] = v[j];
         } else {
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                const double r = zin[j * g.Nz + i] - v[j];
-                betaout[j * g.Nz + i] = betain[j * g.Nz + i] + c.tau * r;
+                const double r = zin[j * g.Nc + i] - v[j];
+                betaout[j * g.Nc + i] = betain[j * g.Nc + i] + c.tau * r;
             }
         }
         cur = nxt;
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_gather_tail(Grid g, const do
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = g.ncl - 1;
-    auto w = [&](int j, i64 cell) { return z[j * g.Nz + cell] + beta[j * g.Nz + cell]; };
+    auto w = [&](int j, i64 cell) { return z[j * g.Nc + cell] + beta[j * g.Nc + cell]; };
     if (y < g.ny && x < g.nx - 1) {
         double acc = w(3, y + g.py * ((x + 1) + g.nx * tl));
         acc += w(4, y + g.py * (x + g.nx * tl));

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             const EdgeQuad nxt = load_edges(g, a.q, yc, xc, tl + 1, c.sf);
             double b[10], v[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nz + i);
+            for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nc + i);
             if (a.bpend) {
 #pragma unroll
                 for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
@@ -97,11 +97,11 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
                 if (own && inb) {
                     if (MODE != 3) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, b[j]);
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nc + i, b[j]);
                     }
                     if (MODE == 2 || MODE == 3) {
 #pragma unroll
-                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nz + i, zo[j]);
+                        for (int j = 0; j < 10; ++j) st_stream<NT>(a.z_out + j * g.Nc + i, zo[j]);
                     }
                 }
                 curo = nxto;

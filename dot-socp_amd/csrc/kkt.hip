@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
     double S[S_COUNT];
 #pragma unroll
     for (int i = 0; i < S_COUNT; ++i) S[i] = 0.0;
-    WBeta WB{beta, g.Nz};
+    WBeta WB{beta, g.Nc};
     auto wgt = [&](i64 idx) { return WEIGHTED ? weight[idx] : 1.0; };
     // rhoT of a cell = kappa * (w .* alpha)_0 ; 0 outside the time range (zero padding of movmean)
     auto rhoT_at = [&](i64 yy, i64 xx, i64 tl) -> double {
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt(Grid g, LoopCoef c, KktC
                 double zs = 0.0, bs = 0.0, rs = 0.0;
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
-                    const double zv = z[j * g.Nz + node], bv = beta[j * g.Nz + node];
+                    const double zv = z[j * g.Nc + node], bv = beta[j * g.Nc + node];
                     zz[j] = zv;
                     p[j] = zv - k.sigma * bv;
                     zs += zv * zv;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 const double q0 = a.q[i];
                 double v[10], zo[10];
 #pragma unroll
-                for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nz + i);
+                for (int j = 0; j < 10; ++j) b[j] = ld_stream<NT>(a.beta_in + j * g.Nc + i);
                 if (a.bpend) {
 #pragma unroll
                     for (int j = 0; j < 10; ++j) b[j] = b[j] * a.bmul / a.bdiv;
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_cells(Grid g, LoopCoef c
                 }
                 if (own && !NORMS) {
 #pragma unroll
-                    for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nz + i, b[j]);
+                    for (int j = 0; j < 10; ++j) st_stream<NT>(a.beta_out + j * g.Nc + i, b[j]);
                     // ||z - Pi_Q(z - sigma beta')||^2 (:240-241) with proj_row's arithmetic, the projected row never
                     // stored: x = z - sigma beta' is cheap to form twice, ten registers are not
                     auto xj = [&](int j) { return zo[j] - k.sigma * b[j]; };

@@ -126,6 +126,7 @@ struct Solver {
     int xcopy(Slab &from, const double *src, Slab &to, double *dst, i64 count);
     int xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, double *dst, size_t dpitch, size_t width,
                 size_t height);
+    i64 column_pad() const;
     i64 row_pitch() const;             // row pitch of this context's device arrays (ny unless the single slab is pitched)
     int sync_all();                    // host waits for every stream of every slab
     // rows of `rowlen` doubles between a device array with rows `pitch` apart and a host array in the reference layout

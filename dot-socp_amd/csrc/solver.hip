@@ -292,6 +292,13 @@ int Solver::ensure_alloc() {
 // no multiple of 16 doubles -- the 2^k+1 grids of the reference's multilevel driver -- padded to the next multiple of
 // 128 bytes; time-slab contexts keep the reference layout (their messages and the partitioned t-solve index the
 // (y, x) columns of a layer linearly).  DOTSOCP_PITCH=0: never.
+// pad between the ten columns of z and beta (common.h: Grid::Nc); DOTSOCP_COLPAD=0: none
+i64 Solver::column_pad() const {
+    const char *e = getenv("DOTSOCP_COLPAD");
+    const i64 v = e ? atoll(e) : 48;
+    return (v > 0 && ny * nx >= 4096) ? v : 0;
+}
+
 i64 Solver::row_pitch() const {
     static const bool on = !(getenv("DOTSOCP_PITCH") && atoi(getenv("DOTSOCP_PITCH")) == 0);
     if (!on || world != 1 || ny <= 16) return ny;
@@ -337,13 +344,13 @@ int Solver::alloc_slabs(int first, int count) {
         if (!s.res) return DOTSOCP_EHIP;
         i64 t0, t1;
         dotsocp_slab_range_impl(nt, world, s.index, &t0, &t1);
-        s.g.set(ny, nx, nt, t0, t1 - t0, row_pitch());
+        s.g.set(ny, nx, nt, t0, t1 - t0, row_pitch(), column_pad());
         const Grid &g = s.g;
         DS_CHECK(dzalloc(&s.phi, g.NphiAlloc, s.st));
         DS_CHECK(dzalloc(&s.q, g.NqAlloc, s.st));
         DS_CHECK(dzalloc(&s.alpha, g.NqAlloc, s.st));
-        DS_CHECK(dzalloc(&s.z, 10 * g.Nz, s.st));
-        DS_CHECK(dzalloc(&s.beta, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.z, 10 * g.Nc, s.st));
+        DS_CHECK(dzalloc(&s.beta, 10 * g.Nc, s.st));
         DS_CHECK(dzalloc(&s.c, g.Nphi, s.st));
         // pitched rows: the pad entries are never written by the tile kernels, so they are zeroed once here -- the few
         // kernels that stream over whole arrays (scalings, sums of squares) then leave them zero / add nothing
@@ -362,8 +369,8 @@ int Solver::alloc_slabs(int first, int count) {
             fused_geometry(g, s.fg);
             DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, s.st));
             DS_CHECK(dzalloc(&s.q2, g.NqAlloc, s.st));
-            if (g.py > g.ny) DS_CHECK(dzalloc(&s.beta2, 10 * g.Nz, s.st));
-            else DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
+            if (g.py > g.ny || g.Nc > g.Nz) DS_CHECK(dzalloc(&s.beta2, 10 * g.Nc, s.st));
+            else DS_CHECK(dmalloc(&s.beta2, 10 * g.Nc));
             DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, s.st));
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, s.st));
             DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, s.st));
@@ -907,10 +914,10 @@ static int copy_field(Solver &S, int field, double *host, bool up) {
             case DOTSOCP_F_Z: case DOTSOCP_F_BETA: {
                 double *d = field == DOTSOCP_F_Z ? s.z : s.beta;
                 const int K = S.prob.dim == 1 ? 6 : 10;
-                if (up && S.prob.dim == 1) DS_HIP(ds_memset_async(d, 0, sizeof(double) * 10 * g.Nz, cur));
+                if (up && S.prob.dim == 1) DS_HIP(ds_memset_async(d, 0, sizeof(double) * 10 * g.Nc, cur));
                 for (int j = 0; j < K; ++j) {
                     const int pj = S.prob.dim == 1 ? k1dCols[j] : j;
-                    DS_CHECK(nodes(d + pj * g.Nz, host + j * NzG + hplane * t0, g.ncl));
+                    DS_CHECK(nodes(d + pj * g.Nc, host + j * NzG + hplane * t0, g.ncl));
                 }
                 break;
             }
@@ -1025,8 +1032,8 @@ void Solver::update_coef() {
 int Solver::flush_beta() {
     if (!bpend) return 0;
     FOR_SLABS(s) {
-        DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul, bdiv, s.st));
-        if (bpend > 1) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nz, bmul2, bdiv2, s.st));
+        DS_CHECK(launch_scale(s.beta, 10 * s.g.Nc, bmul, bdiv, s.st));
+        if (bpend > 1) DS_CHECK(launch_scale(s.beta, 10 * s.g.Nc, bmul2, bdiv2, s.st));
     }
     bpend = 0;
     return 0;
@@ -1079,12 +1086,12 @@ int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
         if (with_c) DS_CHECK(launch_scale(s.c, g.Nphi, a_mul, a_div, s.st));
         if (!acc_light) DS_CHECK(launch_scale(s.alpha, g.NqAlloc, a_mul, a_div, s.st));
         // (acc_light: acc-ADMM's sigma update with the extrapolating cone pass to follow, which divides beta itself)
-        if (!(fused && begun) && !acc_light) DS_CHECK(launch_scale(s.beta, 10 * g.Nz, a_mul, a_div, s.st));
+        if (!(fused && begun) && !acc_light) DS_CHECK(launch_scale(s.beta, 10 * g.Nc, a_mul, a_div, s.st));
         if (q_div != 1.0) {
             DS_CHECK(launch_scale(s.q, g.NqAlloc, 1.0, q_div, s.st));
             // fused dataflow: a z that is not materialised is not scaled either -- it is regenerated from the scaled
             // q and beta when somebody asks for it (the kept beta^k / q^k pair of the last KKT pass no longer matches)
-            if (!(fused && begun) || z_valid) DS_CHECK(launch_scale(s.z, 10 * g.Nz, 1.0, q_div, s.st));
+            if (!(fused && begun) || z_valid) DS_CHECK(launch_scale(s.z, 10 * g.Nc, 1.0, q_div, s.st));
         }
     }
     if (q_div != 1.0 && fused && begun && !z_valid) z_prev_ok = false;

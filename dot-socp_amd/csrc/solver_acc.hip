@@ -30,7 +30,7 @@ int Solver::acc_alloc() {
             fused_geometry(g, s.fg);
             DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, s.st));
             DS_CHECK(dzalloc(&s.q2, g.NqAlloc, s.st));
-            DS_CHECK(dmalloc(&s.beta2, 10 * g.Nz));
+            DS_CHECK(dmalloc(&s.beta2, 10 * g.Nc));
             DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, s.st));
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, s.st));
             DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, s.st));
@@ -38,12 +38,12 @@ int Solver::acc_alloc() {
         if (s.phi_p) continue;
         DS_CHECK(dzalloc(&s.phi_p, g.NphiAlloc, s.st));
         DS_CHECK(dzalloc(&s.alpha_p, g.NqAlloc, s.st));
-        DS_CHECK(dzalloc(&s.z_p, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.z_p, 10 * g.Nc, s.st));
         DS_CHECK(dzalloc(&s.phi_a, g.NphiAlloc, s.st));
         DS_CHECK(dzalloc(&s.q_a, g.NqAlloc, s.st));
         DS_CHECK(dzalloc(&s.alpha_a, g.NqAlloc, s.st));
-        DS_CHECK(dzalloc(&s.z_a, 10 * g.Nz, s.st));
-        DS_CHECK(dzalloc(&s.beta_a, 10 * g.Nz, s.st));
+        DS_CHECK(dzalloc(&s.z_a, 10 * g.Nc, s.st));
+        DS_CHECK(dzalloc(&s.beta_a, 10 * g.Nc, s.st));
     }
     return 0;
 }
@@ -58,8 +58,8 @@ int Solver::acc_set_anchors() {
         DS_HIP(cp(s.phi_a, s.phi, g.NphiAlloc));
         DS_HIP(cp(s.q_a, s.q, g.NqAlloc));
         DS_HIP(cp(s.alpha_a, s.alpha, g.NqAlloc));
-        DS_HIP(cp(s.z_a, s.z, 10 * g.Nz));
-        DS_HIP(cp(s.beta_a, s.beta, 10 * g.Nz));
+        DS_HIP(cp(s.z_a, s.z, 10 * g.Nc));
+        DS_HIP(cp(s.beta_a, s.beta, 10 * g.Nc));
     }
     return 0;
 }
@@ -99,7 +99,7 @@ int Solver::acc_on_sigma_factor(double factor) {
     if (acc_light) return 0;
     FOR_SLABS(s) {
         DS_CHECK(launch_scale(s.alpha_p, s.g.NqAlloc, 1.0, factor, s.st));
-        DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nz, 1.0, factor, s.st));
+        DS_CHECK(launch_scale(s.beta2, 10 * s.g.Nc, 1.0, factor, s.st));
     }
     if (acc_halpern) DS_CHECK(acc_set_anchors());
     return 0;
@@ -334,8 +334,8 @@ int Solver::acc_step(bool *brk) {
             std::swap(s.z, s.z_p);                         // the cone pass wrote the new state there
             std::swap(s.beta, s.beta2);
         } else {
-            DS_CHECK(launch_acc_interp(s.z, s.z_p, s.z_a, 10 * g.Nz, k2, mode, write_aux, s.st));
-            DS_CHECK(launch_acc_interp(s.beta, s.beta2, s.beta_a, 10 * g.Nz, k2, mode, write_aux, s.st));
+            DS_CHECK(launch_acc_interp(s.z, s.z_p, s.z_a, 10 * g.Nc, k2, mode, write_aux, s.st));
+            DS_CHECK(launch_acc_interp(s.beta, s.beta2, s.beta_a, 10 * g.Nc, k2, mode, write_aux, s.st));
         }
     }
     acc_gather_valid = fold || post;

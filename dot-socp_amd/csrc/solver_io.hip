@@ -108,7 +108,7 @@ int Solver::jump_from(Solver &coarse) {
                 if (a > b) continue;
                 for (int j = 0; j < 10; ++j)
                     DS_CHECK(pull(f, tmp + (i64)j * nl * planec + planec * (a - cA), c,
-                                  c.beta + (i64)j * c.g.Nz + planec * (a - c.g.t0), planec * (b - a + 1)));
+                                  c.beta + (i64)j * c.g.Nc + planec * (a - c.g.t0), planec * (b - a + 1)));
             }
             DS_CHECK(launch_prolong_beta(gf, gc0, tmp, f.beta, f.z, coarse.sigma, coarse.cScale * coarse.E, 1.0 / cScale / E,
                                          f.st, cA, nl * planec));
@@ -143,7 +143,7 @@ int Solver::jump_from(Solver &coarse) {
     FOR_SLABS(f) {
         DS_CHECK(launch_grad(f.g, lc, f.phi, f.q, f.st));
         DS_CHECK(scale_owned(f, f.q, 1.0, false));
-        DS_HIP(ds_memset_async(f.z, 0, sizeof(double) * 10 * f.g.Nz, f.st));       // var.z of initialize.m
+        DS_HIP(ds_memset_async(f.z, 0, sizeof(double) * 10 * f.g.Nc, f.st));       // var.z of initialize.m
     }
     DS_CHECK(sync_all());
     return 0;

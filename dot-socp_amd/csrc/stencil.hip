@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_qstep(Grid g, LoopCoef c, co
     const i64 y = (i64)blockIdx.x * TILE_Y + threadIdx.x;
     const i64 x = (i64)blockIdx.y * TILE_X + threadIdx.y;
     const i64 tl = blockIdx.z;
-    WSum W{z, beta, g.Nz};
+    WSum W{z, beta, g.Nc};
     const i64 node = y + g.py * (x + g.nx * tl);
     if (SEG == 0) {
         if (y >= g.ny || x >= g.nx) return;
@@ -980,13 +980,13 @@ __global__ void __launch_bounds__(TILE_Y *TILE_X) k_kkt_tail(Grid g, const doubl
         a0w[y + g.py * x] = weight ? weight[cidx] * a : a;
     }
     if (y < g.ny && x < g.nx - 1) {
-        double acc = beta[3 * g.Nz + y + g.py * ((x + 1) + g.nx * tl)];
-        acc += beta[4 * g.Nz + y + g.py * (x + g.nx * tl)];
+        double acc = beta[3 * g.Nc + y + g.py * ((x + 1) + g.nx * tl)];
+        acc += beta[4 * g.Nc + y + g.py * (x + g.nx * tl)];
         bt_bx[y + g.py * x] = acc;
     }
     if (y < g.ny - 1 && x < g.nx) {
-        double acc = beta[7 * g.Nz + (y + 1) + g.py * (x + g.nx * tl)];
-        acc += beta[8 * g.Nz + y + g.py * (x + g.nx * tl)];
+        double acc = beta[7 * g.Nc + (y + 1) + g.py * (x + g.nx * tl)];
+        acc += beta[8 * g.Nc + y + g.py * (x + g.nx * tl)];
         bt_by[y + g.pyb * x] = acc;
     }
 }

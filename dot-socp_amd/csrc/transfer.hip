@@ -94,7 +94,7 @@ int launch_prolong_beta(const Grid &gf, const Grid &gc, const double *betac, dou
     if (gf.ncl <= 0) return 0;
     dim3 grid((unsigned)((gf.ny + TILE_Y - 1) / TILE_Y), (unsigned)((gf.nx + TILE_X - 1) / TILE_X), (unsigned)gf.ncl);
     DS_KLAUNCH(k_prolong_beta, grid, dim3(TILE_Y, TILE_X), 0, st, gf.ny, gf.nx, gf.py, gf.t0, tc0, gc.py, gc.nx,
-                       Nzc < 0 ? gc.Nz : Nzc, gf.Nz, betac, betaf, neg, sc_in0, sc_in1, sc_out);
+                       Nzc < 0 ? gc.Nc : Nzc, gf.Nc, betac, betaf, neg, sc_in0, sc_in1, sc_out);
     DS_HIP(hipGetLastError());
     return 0;
 }
