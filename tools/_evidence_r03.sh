@@ -1,7 +1,7 @@
 # round-3 evidence run (one MI355X): bench lines, rocprofv3 kernel tables (1024 and 1025 grids), PMC traffic of both grids,
 # rank share of the 8-way split, loop variants, end-to-end multilevel solves
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/ev4
+O=$GRAFT_REPO_ROOT/gpurun_out/ev5
 mkdir -p $O
 B="timeout -k 10 400 python bench.py"
 $B > $O/r03_bench_default.json 2> $O/err.txt; echo default done
@@ -43,5 +43,6 @@ rm -rf $O/prof_a $O/prof_b $O/prof_c $O/prof_d
 timeout -k 10 600 python demos/multilevel_large.py 257 65 3 513 129 4 1025 129 4 > $O/r03_multilevel_large.log 2>> $O/err.txt
 timeout -k 10 300 python demos/demo_dot2d.py > $O/r03_demo_dot2d.log 2>> $O/err.txt
 timeout -k 10 900 python tools/parity_fullsize.py 4 1024 128 inPALM > $O/r03_parity_1024x1024x128_inPALM_K4.log 2>&1
+timeout -k 10 900 python tools/parity_fullsize.py 4 1025 129 inPALM > $O/r03_parity_1025x1025x129_inPALM_K4.log 2>&1
 tail -6 $O/r03_parity_1024x1024x128_inPALM_K4.log
 ls $O | head -80; tail -5 $O/err.txt
