@@ -150,6 +150,29 @@ def cpu_baseline(workload, ny, nx, nt, budget_s):
     }
 
 
+def copy_rate_gbs(torch, device):
+    """Device-to-device copy rate of a 1 GiB buffer in GB/s (bytes read + written over HIP-event time, best of 5): tells
+    the pool's two kinds of boxes apart from the bench line itself."""
+    try:
+        a = torch.empty(1 << 27, dtype=torch.float64, device=f"cuda:{device}")
+        b = torch.empty_like(a)
+        a.zero_()
+        b.copy_(a)
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            best = max(best, 2.0 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        torch.cuda.empty_cache()
+        return round(best, 1)
+    except Exception:
+        return None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without an outer launcher: start the N ranks as fresh child processes (this
     process has neither imported torch nor touched HIP, and it never execs), relay rank 0's JSON line and exit
@@ -260,8 +283,12 @@ def main():
         if args.workload != "dot2d":
             raise SystemExit("multi-GPU bench runs the dot2d workload")
 
-    opts = dict(tau=1.0 if args.method == "ALG2" else 1.9, sigma=1.0, tol=0.0, maxit=args.warmup + args.steps, scaling=True,
-                ifCheckStepByStep=False, time_limit=1e9)
+    # --rank-share: a rank's iteration is ~1.7 ms and issues ~40 launches; the ~20 per-phase HIP events per iteration that feed
+    # `kernel_ms` cost it 4-5 % (they cost the 11 ms full-grid iteration nothing measurable).  Its timed pass therefore runs
+    # WITHOUT them and a second, untimed pass of the same length WITH them fills `kernel_ms` / `roofline`
+    two_pass = bool(share) and not os.environ.get("DOTSOCP_BENCH_NOPROF")
+    opts = dict(tau=1.0 if args.method == "ALG2" else 1.9, sigma=1.0, tol=0.0,
+                maxit=args.warmup + args.steps * (2 if two_pass else 1), scaling=True, ifCheckStepByStep=False, time_limit=1e9)
     if share:
         # the middle slab of the N-way split: both neighbours exist, every exchange of a real rank takes place
         weight = None
@@ -289,9 +316,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    box_copy_gbs = copy_rate_gbs(torch, device)
     done = ctx.run(args.warmup)
     assert done == args.warmup
-    if not os.environ.get("DOTSOCP_BENCH_NOPROF"):
+    if not os.environ.get("DOTSOCP_BENCH_NOPROF") and not two_pass:
         D.capi.check(D.capi.lib().dotsocp_set_profiling(ctx._ctx, 1))
     fence()
     t0 = time.perf_counter()
@@ -299,6 +327,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     assert done == args.steps
+    if two_pass:
+        D.capi.check(D.capi.lib().dotsocp_set_profiling(ctx._ctx, 1))
+        assert ctx.run(args.steps) == args.steps
+        fence()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -335,6 +367,12 @@ def main():
     else:                                     # DOTSOCP_FUSED=0: plain projection kernel, beta in + q in + z out
         kname, (proj_ms, proj_n) = "k_cone_march<0> (cone projection)", times["cone_proj"]
         alg_bytes = 8.0 * (20 * Nz + Nq)
+    # time-slab mode: the cone pass of an iteration runs as two timed intervals (the chunks in front of the last one, then the
+    # last chunk, which alone reads the q halo): the average interval covers half of the slab's cells
+    slab_mode = world > 1 or args.nslabs > 1 or bool(share)
+    cone_parts = 2 if (slab_mode and ncl >= 12 and os.environ.get("DOTSOCP_OVERLAP", "1") != "0"
+                       and os.environ.get("DOTSOCP_SPLIT_CONE", "1") != "0" and args.method in ("inPALM", "ALG2")) else 1
+    alg_bytes /= cone_parts
     achieved = alg_bytes / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
     # HBM bytes of the dominant kernel by the PMC counters: a figure of the builder's profiling run of THIS round's build
     # (profiles/cone_proj_traffic.json, separate --pmc FETCH_SIZE / WRITE_SIZE passes), not of this run -- tagged as such,
@@ -385,10 +423,14 @@ def main():
         "config": {"workload": f"{args.workload} {ny}x{nx}x{nt} Gaussian-to-Gaussian (Example 5.1), " + {
                        "inPALM": "inPALM tau=1.9", "ALG2": "ALG2 tau=1.0", "PALM": "PALM tau=1.9",
                        "acc-ADMM": "acc-ADMM (Halpern, rho=2, restart=100)"}[args.method] + ", levelN=1",
-                   "grid": [ny, nx, nt], "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
+                   "grid": [ny, nx, nt],
+                   "kkt_checks_in_timed_region": int(np.sum((hist["iter"] > args.warmup) & (hist["iter"] <= args.warmup + args.steps))),
+                   # which kind of box this run landed on: device-to-device copy rate of a 1 GiB buffer measured right
+                   # before the warm-up (read + write bytes / time; the pool's two kinds differ by ~10 % in every HBM-bound kernel)
+                   "box_copy_gbs": box_copy_gbs,
                    # the timed region runs with the library's per-phase HIP events switched on (they feed roofline and
                    # kernel_ms); DOTSOCP_BENCH_NOPROF=1 times it without them
-                   "per_phase_hip_events_in_timed_region": not bool(os.environ.get("DOTSOCP_BENCH_NOPROF")),
+                   "per_phase_hip_events_in_timed_region": not bool(os.environ.get("DOTSOCP_BENCH_NOPROF")) and not two_pass,
                    "parallelism": (f"rank share: slab {share // 2} of {share} time slabs on 1 GPU, neighbour messages as local "
                                    f"copies (timing only, not a valid solve)") if share else
                                   ("1 GPU" if world == 1 else f"{world} time slabs")},
@@ -405,14 +447,14 @@ def main():
     if share:
         out["rank_share"] = {"n": share, "slab": share // 2, "time_nodes": int(ntl),
                              "kernel_ms_sum": round(sum(v[0] * v[1] for v in times.values()) / max(args.steps, 1), 4),
+                             "timed_pass": "without per-phase HIP events; kernel_ms / roofline come from a second pass of the same "
+                                           "length with them" if two_pass else "with per-phase HIP events",
                              "note": "kernel_ms_sum = per-iteration sum of the phase timers (HIP events on the launch streams; "
                                      "phases on the second stream overlap the main one); ms_per_step - overlap-free kernel time = "
                                      "launch / dependency chain + host"}
-    if world > 1 or args.nslabs > 1 or share:
-        # time-slab mode: the timed interval covers both chunk launches of the slab's cone pass on the second stream --
-        # they share HBM with the Poisson solve on the main stream and wait for the q halo in between; the N = 1 line
-        # is the kernel's roofline figure
-        out["roofline"]["note"] = "interval spans two chunk launches overlapped with the phi-step and the halo wait"
+    if slab_mode:
+        out["roofline"]["note"] = (f"time slabs: the cone pass of an iteration is {cone_parts} timed interval(s) (chunks of time cells, "
+                                   "one launch each); bytes and time are per interval; the N = 1 line is the kernel's roofline figure")
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.method == "inPALM" and not share:
             out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)

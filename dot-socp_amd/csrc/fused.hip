@@ -54,13 +54,21 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
     const i64 t1 = (t0 + a.TC < g.ncl) ? t0 + a.TC : g.ncl;
     const bool lastChunk = (t1 == g.ncl);
     constexpr bool GATHER = (PROJ || MODE == 4);
-    const i64 tstart = (GATHER && t0 > 0) ? t0 - 1 : t0;
+    // chunks launched one after the other hand the "t + 1" cone entries of their last cell to the next chunk through
+    // a.carry (four planes of one layer) instead of having it recompute that cell (reads of twenty planes)
+    const bool carried = GATHER && !DUAL && t0 > 0 && a.carry_in != nullptr;
+    const i64 tstart = (GATHER && t0 > 0 && !carried) ? t0 - 1 : t0;
     const i64 nxblk = gridDim.y, nyblk = gridDim.x;
 
     EdgeQuad cur = load_edges(g, a.q, yc, xc, tstart, c.sf), curo, cur3;
     if (UPD) curo = load_edges(g, a.q_old, yc, xc, tstart, c.sf);
     if (MODE == 5) cur3 = load_edges(g, a.q3, yc, xc, tstart, c.sf);
     GatherCarry gc, gcp;
+    if (carried) {
+        const i64 ci = yc + g.py * xc;
+        gc.p3 = a.carry_in[ci]; gc.p4 = a.carry_in[g.plane + ci];
+        gc.p7 = a.carry_in[2 * g.plane + ci]; gc.p8 = a.carry_in[3 * g.plane + ci];
+    }
     // one extra virtual step (tl == ncl, no cell) on the last chunk emits the final edge layer
     const i64 tstop = (GATHER && lastChunk) ? t1 + 1 : t1;
     for (i64 tl = tstart; tl < tstop; ++tl) {
@@ -150,6 +158,11 @@ __global__ void __launch_bounds__(64 * XB) k_cone_fused(Grid g, LoopCoef c, Fuse
             gather_finish<XB>(g, c.sf, xchp, gcp, wp, tl, own && inb, x, y, xl, lane, nxblk, nyblk, blk.y, blk.x,
                               a.p2, a.sxp, a.syp);
         }
+    }
+    if (GATHER && !DUAL && !lastChunk && a.carry_out != nullptr && inb) {
+        const i64 ci = y + g.py * x;
+        a.carry_out[ci] = gc.p3; a.carry_out[g.plane + ci] = gc.p4;
+        a.carry_out[2 * g.plane + ci] = gc.p7; a.carry_out[3 * g.plane + ci] = gc.p8;
     }
 }
 

@@ -74,6 +74,10 @@ struct FusedArgs {
     double bmul2, bdiv2;    // second pending operation, applied after the first
     int xcd;                // permute the tile order so that y-neighbouring tiles share an XCD (device_utils.h)
     int z0;                 // first chunk of this launch (launch_cone_fused can launch a range of chunks)
+    // chunks launched ONE PER LAUNCH in ascending order on one stream (time slabs): the last cell's "t + 1" cone entries
+    // w3, w4, w7, w8 travel to the next chunk through four layer planes instead of that chunk recomputing the cell
+    const double *carry_in; // read by a chunk that is not the first (nullptr: recompute the cell in front)
+    double *carry_out;      // written by a chunk that is not the last (may be the buffer carry_in points to)
 };
 // rows that are not a multiple of 16 doubles (128 bytes): neighbouring tiles share cache lines (2^k+1 grids)
 bool tile_xcd_remap(const Grid &g);
@@ -155,6 +159,7 @@ struct QStepExtra {
     double amul, adiv;
     double *partials, *resid;
     double kappa, dsD;       // KktCoef
+    double *u0_tail;         // time slabs: w.*q0^+ - alpha0^+ of the last owned cell layer goes here too (the right slab's rhs)
 };
 int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, const double *phi, const double *q2,
                      const double *sx, const double *sy, const double *weight, const double *tail_bx,
@@ -165,7 +170,8 @@ i64 qstep_rhs_blocks(const Grid &g, const FusedGeom &fg);
 // rhs <- (rhs + r) - r / factor, c <- c / factor  (sigma update without a new pass over q and alpha)
 int launch_rhs_sigma_fix(double *rhs, const double *r, double *cvec, i64 n, double factor, hipStream_t st);
 // chunks of time layers of that launch (z0 + i * zstride, i < zcount, selects chunks; chunks are independent of each other: only
-// chunk 0 reads the adjoint tails of the left neighbour slab and only the last one the phi halo of the right one)
+// chunk 0 reads the adjoint tails of the left neighbour slab and only the last one the phi halo of the right one -- and
+// writes the u0 tail)
 i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TC = nullptr);
 // acc-ADMM: q-step + multiplier + next rhs (var 1: raw q^+, alpha^+; var 2: raw q^+ plus the Halpern step of q in
 // place in q_state and of alpha into alpha_out, buffers other than alpha_in)
@@ -212,7 +218,7 @@ int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, con
                      const double *r, double *send, hipStream_t st);
 int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                        int rank, i64 l0, i64 nl, const i64 *slab_n, const double *recv, double *back, double *zero_work,
-                       hipStream_t st);
+                       hipStream_t st, const double *own_recv = nullptr, double *own_back = nullptr);
 int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                      const double *back, double *x, double *qinv, hipStream_t st);
 // up to DS_MAX_WORLD messages copied by ONE launch on the receiving slab's stream: message m = count[m] doubles from

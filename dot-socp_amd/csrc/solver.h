@@ -57,8 +57,9 @@ struct Slab {
     int index = 0;              // global slab number
     int dev = 0;                // HIP device this slab lives on
     hipStream_t st = nullptr;   // main stream of the slab (slab 0: Solver::stream)
-    hipStream_t st_z = nullptr; // second stream: cone pass / middle q-step chunks when they overlap the rest
+    hipStream_t st_z = nullptr; // second stream: carries the slab's communication in time-slab mode (Solver::comm_z)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_cjoin = nullptr;        // synchronous communication on the second stream: "done" (Solver::comm_leave)
     hipEvent_t xev[DS_XEV] = {nullptr};   // ordering of cross-slab copies (Solver::xcopy), used round-robin
     hipEvent_t ev_tri = nullptr;          // "this slab's interface message is written" (Solver::tri_exchange, slabs of one process)
     hipEvent_t ev_msg = nullptr, ev_got = nullptr;   // batched neighbour exchanges: "my messages are written" / "I have pulled mine"
@@ -90,6 +91,7 @@ struct Slab {
     double *alpha2 = nullptr;   // ping-pong partner of alpha (q-step that also forms the next rhs)
     // partitioned tridiagonal t-solve (tri.hip): messages to / from the owners of the modes, zero-mode work line
     double *tri_send = nullptr, *tri_recv = nullptr, *tri_bsend = nullptr, *tri_brecv = nullptr, *tri_zero = nullptr;
+    double *carry = nullptr;    // 4 layer planes: hand-off between the chunk launches of a cone pass (FusedArgs::carry_in / _out)
     FusedGeom fg{};
     // acc-ADMM loop (solver_acc.hip): x^+ of the iteration (q^+ lives in q_old, beta^+ in beta2) and the
     // Halpern anchors / previous extrapolation points
@@ -131,7 +133,23 @@ struct Solver {
     int sync_all();                    // host waits for every stream of every slab
     // rows of `rowlen` doubles between a device array with rows `pitch` apart and a host array in the reference layout
     int copy_rows(double *dev, double *host, i64 rowlen, i64 pitch, i64 nrows, bool up, hipStream_t st);
-    int fork_z();                      // every slab's second stream starts behind what its main stream holds so far
+    // Time slabs: every message between slabs travels on the slab's SECOND stream (RCCL calls, pull launches, peer copies),
+    // kernels stay on the main stream.  A communication step is bracketed by comm_enter() / comm_leave(): the second
+    // stream first waits for what the main stream holds (fork), and the main stream then waits for the messages (join) --
+    // the synchronous form every caller gets by default.  Solver::step() instead runs the iteration's exchanges
+    // asynchronously (comm_async): it forks, issues the exchange, marks an event on the second stream, enqueues kernels
+    // that do not need the message on the main stream and lets the main stream wait for the mark only in front of the
+    // first kernel that does -- the messages travel while kernels run, and no two kernels ever compete for the compute
+    // units (measured: a cone pass on a second stream stretched the whole-CU DCT passes beside it from 60 to 400 us)
+    bool comm_z = false;               // communication on the second streams (time-slab mode; DOTSOCP_OVERLAP=0: on the main stream)
+    bool comm_async = false;           // inside an asynchronous exchange of step(): comm_enter / comm_leave do nothing
+    int comm_depth = 0;
+    hipStream_t cst(const Slab &s) const { return comm_z ? s.st_z : s.st; }
+    int comm_enter();
+    int comm_leave();
+    int comm_fork();                               // second streams wait for the main streams
+    int comm_mark(hipEvent_t Slab::*ev);           // record on the second streams
+    int comm_wait(hipEvent_t Slab::*ev);           // main streams wait
     bool overlap = false;              // DOTSOCP_OVERLAP=0/1 overrides (default: on in time-slab mode)
     std::vector<Slab> slabs;        // the slabs held by THIS process
     // one host thread per slab issues that slab's launches while run() is active (defer.h); null: the caller's thread
@@ -217,12 +235,18 @@ struct Solver {
     bool remote() const { return nccl != nullptr; }
     int step(bool *brk);
     int rescale_block();
-    int phase_phi();
-    // on_z: on every slab's second stream; part 0: all chunks; 1: all but the last chunk; 2: the last chunk
-    int phase_z(bool on_z, int part = 0);
+    // hooks of the asynchronous schedule inside the partitioned t-solve: `fill` runs on the main streams while the first
+    // interface exchange travels, `behind` right after the second one has been issued
+    struct PhiHooks { std::function<int()> fill, behind; };
+    int phase_phi(const PhiHooks *hooks = nullptr);
+    // part 0: all chunks; 1: all but the last chunk; 2: the last chunk (the only one that reads the q halo)
+    int phase_z(int part = 0);
     int phase_z_tails();
-    int ship_tails();        // time slabs: finalise + send the adjoint tails (-> right) and the phi head (-> left)
-    // part 0: whole q-step; 1: the middle chunks on the second streams; 2: first + last chunk, then finish
+    int make_tails();        // time slabs: finalise the adjoint sums of the last owned cell for the right neighbour
+    int send_tails();        // ... adjoint tails -> right
+    int send_phi_head();     // ... first phi layer -> left
+    int ship_tails();        // all three, one group
+    // part 0: whole q-step; 1: all chunks but the last; 2: the last chunk (the one that reads the phi halo), then finish
     int phase_q(int part = 0, bool kkt = false);
     int phase_mult();
     int materialise();
@@ -237,24 +261,26 @@ struct Solver {
     void prof_begin(int phase, bool on_z = false);
     void prof_end(int phase, bool on_z = false);
     int prof_flush();
-    int poisson_all();
+    int poisson_all(const PhiHooks *hooks = nullptr);
     int transpose(bool forward);
     int exchange_q_halo(bool with_u0);
     int ensure_halo();       // run the q-halo exchange the last q-step left pending (halo_pending)
     int exchange_u0_tail();
+    int make_u0_tail();
     int group_begin();
     int group_end();
     bool tri_tsolve = true;  // time-slab Poisson solve by partitioned tridiagonal systems (tri.hip); DOTSOCP_TSOLVE=dct:
                              // slab <-> pencil transposes around the t-axis DCT instead
     int tri_alloc();
     int tri_exchange(bool back);
-    int poisson_t_tridiag();
+    int poisson_t_tridiag(const PhiHooks *hooks);
     bool qrhs = true;        // DOTSOCP_QRHS=0: separate q-step and rhs kernels
     bool rhs_valid = false;  // w0 holds A'(w.*q - alpha) + c of the current iterate (left there by the q-step)
     // the q halo / u0 tail of the newest iterate have not been exchanged yet: step() issues the exchange behind the
     // fork so that the cone chunks that do not read the halo overlap it; every other reader calls ensure_halo()
     bool halo_pending = false;
     bool u0_fresh = false;   // u0_prev holds w.*q0 - alpha0 of the CURRENT iterate of the left neighbour
+    bool u0_made = false;    // send_plane holds the u0 tail of the current iterate (written by the q-step itself)
     // every slab with a neighbour in direction `dir` (+1 right, -1 left) sends `count` doubles
     // from src(slab) to dst(neighbour)
     typedef std::function<double *(Slab &)> Sel;

@@ -70,56 +70,88 @@ static hipEvent_t next_xev(Slab &s) {
 int Solver::xcopy(Slab &from, const double *src, Slab &to, double *dst, i64 count) {
     if (count <= 0) return 0;
     const size_t bytes = sizeof(double) * (size_t)count;
-    if (from.st == to.st) {
+    DS_CHECK(comm_enter());
+    const hipStream_t fs = cst(from), ts = cst(to);
+    if (fs == ts) {
         DS_CHECK(use(to));
-        DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
-        return 0;
+        DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, ts));
+        return comm_leave();
     }
     hipEvent_t a = next_xev(from), b = next_xev(to);
     DS_CHECK(use(from));
-    DS_HIP(ds_event_record(a, from.st));
+    DS_HIP(ds_event_record(a, fs));
     DS_CHECK(use(to));
-    DS_HIP(ds_stream_wait_event(to.st, a, 0));
-    if (from.dev == to.dev) DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, to.st));
-    else DS_HIP(ds_memcpy_peer_async(dst, to.dev, src, from.dev, bytes, to.st));
-    DS_HIP(ds_event_record(b, to.st));
+    DS_HIP(ds_stream_wait_event(ts, a, 0));
+    if (from.dev == to.dev) DS_HIP(ds_memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, ts));
+    else DS_HIP(ds_memcpy_peer_async(dst, to.dev, src, from.dev, bytes, ts));
+    DS_HIP(ds_event_record(b, ts));
     DS_CHECK(use(from));
-    DS_HIP(ds_stream_wait_event(from.st, b, 0));
-    return 0;
+    DS_HIP(ds_stream_wait_event(fs, b, 0));
+    return comm_leave();
 }
 
 int Solver::xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, double *dst, size_t dpitch, size_t width,
                     size_t height) {
     if (width == 0 || height == 0) return 0;
-    if (from.st == to.st) {
+    DS_CHECK(comm_enter());
+    const hipStream_t fs = cst(from), ts = cst(to);
+    if (fs == ts) {
         DS_CHECK(use(to));
-        DS_HIP(ds_memcpy2d_async(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
-        return 0;
+        DS_HIP(ds_memcpy2d_async(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, ts));
+        return comm_leave();
     }
     hipEvent_t a = next_xev(from), b = next_xev(to);
     DS_CHECK(use(from));
-    DS_HIP(ds_event_record(a, from.st));
+    DS_HIP(ds_event_record(a, fs));
     DS_CHECK(use(to));
-    DS_HIP(ds_stream_wait_event(to.st, a, 0));
+    DS_HIP(ds_stream_wait_event(ts, a, 0));
     if (from.dev == to.dev || peer_ok) {
         // different devices: peer access was enabled in both directions when the slabs were placed (alloc_slabs)
-        DS_HIP(ds_memcpy2d_async(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, to.st));
+        DS_HIP(ds_memcpy2d_async(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, ts));
     } else {
         // peer access refused: row by row through hipMemcpyPeerAsync, which stages through the host by itself
         for (size_t r = 0; r < height; ++r)
-            DS_HIP(ds_memcpy_peer_async((char *)dst + r * dpitch, to.dev, (const char *)src + r * spitch, from.dev, width, to.st));
+            DS_HIP(ds_memcpy_peer_async((char *)dst + r * dpitch, to.dev, (const char *)src + r * spitch, from.dev, width, ts));
     }
-    DS_HIP(ds_event_record(b, to.st));
+    DS_HIP(ds_event_record(b, ts));
     DS_CHECK(use(from));
-    DS_HIP(ds_stream_wait_event(from.st, b, 0));
-    return 0;
+    DS_HIP(ds_stream_wait_event(fs, b, 0));
+    return comm_leave();
 }
 
-// second streams: fork behind everything enqueued on the slab's main stream ...
-int Solver::fork_z() {
+// ---- communication on the second streams (solver.h: comm_z) ----
+int Solver::comm_fork() {
+    if (!comm_z) return 0;
     FOR_SLABS(s) {
         DS_HIP(ds_event_record(s.ev_fork, s.st));
         DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
+    }
+    return 0;
+}
+
+int Solver::comm_mark(hipEvent_t Slab::*ev) {
+    if (!comm_z) return 0;
+    FOR_SLABS(s) DS_HIP(ds_event_record(s.*ev, s.st_z));
+    return 0;
+}
+
+int Solver::comm_wait(hipEvent_t Slab::*ev) {
+    if (!comm_z) return 0;
+    FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.*ev, 0));
+    return 0;
+}
+
+int Solver::comm_enter() {
+    if (!comm_z || comm_async) return 0;
+    if (comm_depth++ == 0) DS_CHECK(comm_fork());
+    return 0;
+}
+
+int Solver::comm_leave() {
+    if (!comm_z || comm_async) return 0;
+    if (--comm_depth == 0) {
+        DS_CHECK(comm_mark(&Slab::ev_cjoin));
+        DS_CHECK(comm_wait(&Slab::ev_cjoin));
     }
     return 0;
 }
@@ -155,6 +187,7 @@ void Solver::free_slabs() {
         if (s.ev_tri) (void)hipEventDestroy(s.ev_tri);
         if (s.ev_msg) (void)hipEventDestroy(s.ev_msg);
         if (s.ev_got) (void)hipEventDestroy(s.ev_got);
+        if (s.ev_cjoin) (void)hipEventDestroy(s.ev_cjoin);
         if (s.st != stream) {        // slab 0 borrows the solver's own streams / events
             if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
             if (s.ev_join) (void)hipEventDestroy(s.ev_join);
@@ -171,6 +204,7 @@ void Solver::free_slabs() {
         dfree(s.kw.partials); dfree(s.kw.sums);
         dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy); dfree(s.alpha2);
         dfree(s.q3); dfree(s.p2); dfree(s.sxp); dfree(s.syp);
+        dfree(s.carry);
         dfree(s.tri_send); dfree(s.tri_recv); dfree(s.tri_bsend); dfree(s.tri_brecv); dfree(s.tri_zero);
         dfree(s.phi_p); dfree(s.alpha_p); dfree(s.z_p);
         dfree(s.phi_a); dfree(s.q_a); dfree(s.alpha_a); dfree(s.z_a); dfree(s.beta_a);
@@ -235,6 +269,15 @@ static void pencil_range(i64 plane, int world, int j, i64 *l0, i64 *l1) {
     *l1 = cut(j + 1);
 }
 
+// The second stream of a slab carries its messages and the small kernels between them (solver.h: comm_z): highest
+// priority, so that their workgroups are placed ahead of the queued workgroups of the bulk kernel on the main stream
+static int make_second_stream(hipStream_t *st) {
+    int least = 0, greatest = 0;
+    DS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    DS_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest));
+    return 0;
+}
+
 int Solver::init(const dotsocp_problem *p, int dev, int nslabs, bool multi_dev) {
     DS_ARG(p != nullptr, "prob is NULL");
     DS_ARG(p->dim == 1 || p->dim == 2, "prob.dim must be 1 or 2");
@@ -261,7 +304,7 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs, bool multi_dev) 
     cur_dev = -1;
     DS_CHECK(use_dev(dev));
     DS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    DS_HIP(hipStreamCreateWithFlags(&stream_z, hipStreamNonBlocking));
+    DS_CHECK(make_second_stream(&stream_z));
     DS_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     DS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     DS_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
@@ -317,6 +360,9 @@ int Solver::alloc_slabs(int first, int count) {
     free_slabs();
     peer_ok = true;
     cross_device = false;
+    comm_z = overlap && world > 1 && fused;      // messages on the second streams (solver.h)
+    comm_depth = 0;
+    comm_async = false;
     slabs.resize(count);
     const i64 plane = ny * nx;
     for (int r = 0; r < count; ++r) {
@@ -330,7 +376,7 @@ int Solver::alloc_slabs(int first, int count) {
             s.ev_fork = ev_fork; s.ev_join = ev_join; s.ev_halo = ev_halo;
         } else {
             DS_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-            DS_HIP(hipStreamCreateWithFlags(&s.st_z, hipStreamNonBlocking));
+            DS_CHECK(make_second_stream(&s.st_z));
             DS_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
             DS_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
             DS_HIP(hipEventCreateWithFlags(&s.ev_halo, hipEventDisableTiming));
@@ -339,6 +385,7 @@ int Solver::alloc_slabs(int first, int count) {
         DS_HIP(hipEventCreateWithFlags(&s.ev_tri, hipEventDisableTiming));
         DS_HIP(hipEventCreateWithFlags(&s.ev_msg, hipEventDisableTiming));
         DS_HIP(hipEventCreateWithFlags(&s.ev_got, hipEventDisableTiming));
+        DS_HIP(hipEventCreateWithFlags(&s.ev_cjoin, hipEventDisableTiming));
         DS_HIP(hipHostMalloc((void **)&s.h_sums, sizeof(double) * S_COUNT));
         s.res = res_for(s.dev);
         if (!s.res) return DOTSOCP_EHIP;
@@ -384,6 +431,7 @@ int Solver::alloc_slabs(int first, int count) {
             DS_CHECK(dmalloc(&s.pencil, s.nl * nt));
             DS_CHECK(dmalloc(&s.pencil2, s.nl * nt));
             DS_CHECK(dmalloc(&s.stage, g.Nphi));
+            if (fused) DS_CHECK(dzalloc(&s.carry, 4 * g.plane, s.st));
             if (!g.first) {
                 DS_CHECK(dzalloc(&s.u0_prev, plane, s.st));
                 DS_CHECK(dzalloc(&s.a0_prev, plane, s.st));
@@ -491,6 +539,7 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
 // --------------------------------------------------------------------------------------
 int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
     if (!multi() || count <= 0) return 0;
+    DS_CHECK(comm_enter());
     if (!remote()) {
         if (msg_batching()) {
             for (size_t i = 0; i + 1 < slabs.size(); ++i) {
@@ -498,25 +547,26 @@ int Solver::shift(int dir, const Sel &src, const Sel &dst, i64 count) {
                 msgs.push_back(Msg{f, t, src(slabs[f]), dst(slabs[t]), count});
             }
             if (msg_depth == 0) DS_CHECK(flush_msgs());       // a lone shift() is a group of one
-            return 0;
+            return comm_leave();
         }
         for (size_t i = 0; i + 1 < slabs.size(); ++i) {
             Slab &from = (dir > 0) ? slabs[i] : slabs[i + 1];
             Slab &to = (dir > 0) ? slabs[i + 1] : slabs[i];
             DS_CHECK(xcopy(from, src(from), to, dst(to), count));
         }
-        return 0;
+        return comm_leave();
     }
     Rccl &api = rccl_api();
     Slab &s = slabs[0];
+    const hipStream_t cs = cst(s);
     const int to = rank + dir, from = rank - dir;
     DS_NCCL(api.GroupStart());
     ++open_groups;
-    if (to >= 0 && to < world) DS_NCCL_G(api.Send(src(s), (size_t)count, ncclDouble, to, (ncclComm_t)nccl, stream));
-    if (from >= 0 && from < world) DS_NCCL_G(api.Recv(dst(s), (size_t)count, ncclDouble, from, (ncclComm_t)nccl, stream));
+    if (to >= 0 && to < world) DS_NCCL_G(api.Send(src(s), (size_t)count, ncclDouble, to, (ncclComm_t)nccl, cs));
+    if (from >= 0 && from < world) DS_NCCL_G(api.Recv(dst(s), (size_t)count, ncclDouble, from, (ncclComm_t)nccl, cs));
     --open_groups;
     DS_NCCL(api.GroupEnd());
-    return 0;
+    return comm_leave();
 }
 
 int Solver::shift_edge_halo(const Sel &base) {
@@ -531,6 +581,7 @@ int Solver::shift_edge_halo(const Sel &base) {
 // Several shift() calls issued as ONE RCCL group (nested groups are legal): traffic to the left and
 // to the right neighbour then shares the bidirectional links instead of queueing behind each other.
 int Solver::group_begin() {
+    DS_CHECK(comm_enter());
     if (remote()) {
         DS_NCCL(rccl_api().GroupStart());
         ++open_groups;
@@ -547,7 +598,7 @@ int Solver::group_end() {
     } else if (--msg_depth == 0) {
         DS_CHECK(flush_msgs());
     }
-    return 0;
+    return comm_leave();
 }
 
 // Pull launches (a kernel on the receiver's device reading the sender's memory through a peer pointer): the default
@@ -576,7 +627,7 @@ int Solver::flush_msgs() {
     for (size_t i = 0; i < P; ++i)
         if (sends[i]) {
             DS_CHECK(use(slabs[i]));
-            DS_HIP(ds_event_record(slabs[i].ev_msg, slabs[i].st));
+            DS_HIP(ds_event_record(slabs[i].ev_msg, cst(slabs[i])));
         }
     for (size_t t = 0; t < P; ++t) {
         if (!gets[t]) continue;
@@ -587,19 +638,19 @@ int Solver::flush_msgs() {
         std::vector<char> waited(P, 0);
         for (const Msg &m : msgs) {
             if (m.to != (int)t || m.count <= 0) continue;
-            if (!waited[m.from] && slabs[m.from].st != to.st) {
-                DS_HIP(ds_stream_wait_event(to.st, slabs[m.from].ev_msg, 0));
+            if (!waited[m.from] && cst(slabs[m.from]) != cst(to)) {
+                DS_HIP(ds_stream_wait_event(cst(to), slabs[m.from].ev_msg, 0));
                 waited[m.from] = 1;
             }
             if (g.n == DS_MAX_WORLD) {
-                DS_CHECK(launch_gather_msgs(g, to.st));
+                DS_CHECK(launch_gather_msgs(g, cst(to)));
                 g.n = 0;
             }
             g.src[g.n] = m.src; g.dst[g.n] = m.dst; g.count[g.n] = m.count;
             ++g.n;
         }
-        DS_CHECK(launch_gather_msgs(g, to.st));
-        DS_HIP(ds_event_record(to.ev_got, to.st));
+        DS_CHECK(launch_gather_msgs(g, cst(to)));
+        DS_HIP(ds_event_record(to.ev_got, cst(to)));
     }
     for (size_t f = 0; f < P; ++f) {
         if (!sends[f]) continue;
@@ -607,8 +658,8 @@ int Solver::flush_msgs() {
         DS_CHECK(use(from));
         std::vector<char> waited(P, 0);
         for (const Msg &m : msgs)
-            if (m.from == (int)f && m.count > 0 && !waited[m.to] && slabs[m.to].st != from.st) {
-                DS_HIP(ds_stream_wait_event(from.st, slabs[m.to].ev_got, 0));
+            if (m.from == (int)f && m.count > 0 && !waited[m.to] && cst(slabs[m.to]) != cst(from)) {
+                DS_HIP(ds_stream_wait_event(cst(from), slabs[m.to].ev_got, 0));
                 waited[m.to] = 1;
             }
     }
@@ -617,14 +668,20 @@ int Solver::flush_msgs() {
 }
 
 // u0 = w.*q0 - alpha0 of every slab's last cell layer -> right neighbour (first node layer of its rhs)
-int Solver::exchange_u0_tail() {
-    if (!multi()) return 0;
+int Solver::make_u0_tail() {
+    if (!multi() || u0_made) return 0;        // (u0_made: the q-step wrote it)
     for (auto &s : slabs)
         if (!s.g.last) {
             DS_CHECK(use(s));
             DS_CHECK(launch_u0_tail(s.g, s.q, s.alpha, s.weight, s.send_plane, s.st));
         }
-    DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
+    return 0;
+}
+
+// (make_u0_tail() first: its kernel runs on the main streams)
+int Solver::exchange_u0_tail() {
+    if (!multi()) return 0;
+    DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, slabs[0].g.plane));
     u0_fresh = true;
     return 0;
 }
@@ -633,7 +690,8 @@ int Solver::exchange_u0_tail() {
 // of the new iterate travels to the right in the same group
 int Solver::exchange_q_halo(bool with_u0) {
     if (!multi()) return 0;
-    prof_begin(PH_COMM);
+    if (with_u0 && !comm_async) DS_CHECK(make_u0_tail());     // (an asynchronous caller has run it before its fork)
+    prof_begin(PH_COMM, comm_z);
     const i64 bxL = slabs[0].g.bxLayer, byL = slabs[0].g.byLayer;
     DS_CHECK(group_begin());
     DS_CHECK(shift(-1, [](Slab &s) { return s.q + s.g.offBx; },
@@ -642,7 +700,7 @@ int Solver::exchange_q_halo(bool with_u0) {
                    [](Slab &s) { return s.q + s.g.offBy + s.g.byLayer * s.g.ntl; }, byL));
     if (with_u0) DS_CHECK(exchange_u0_tail());
     DS_CHECK(group_end());
-    prof_end(PH_COMM);
+    prof_end(PH_COMM, comm_z);
     return 0;
 }
 
@@ -699,30 +757,36 @@ int Solver::transpose(bool forward) {
     if (forward) {
         DS_CHECK(launch_pencil_pack(true, pc, plane, s.g.ntl, s.w0, s.stage, stream));
         DS_CHECK(self_copy(true));
+        DS_CHECK(comm_enter());
+        const hipStream_t cs = cst(s);
         DS_NCCL(api.GroupStart());
         ++open_groups;
         for (int j = 0; j < world; ++j) {
             if (j == rank) continue;
             if (pnl[j] > 0)
-                DS_NCCL_G(api.Send(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Send(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, cs));
             if (s.nl > 0)
-                DS_NCCL_G(api.Recv(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Recv(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, cs));
         }
         --open_groups;
         DS_NCCL(api.GroupEnd());
+        DS_CHECK(comm_leave());
     } else {
         DS_CHECK(self_copy(false));
+        DS_CHECK(comm_enter());
+        const hipStream_t cs = cst(s);
         DS_NCCL(api.GroupStart());
         ++open_groups;
         for (int j = 0; j < world; ++j) {
             if (j == rank) continue;
             if (s.nl > 0)
-                DS_NCCL_G(api.Send(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Send(s.pencil + s.nl * pt0[j], (size_t)(s.nl * pntl[j]), ncclDouble, j, (ncclComm_t)nccl, cs));
             if (pnl[j] > 0)
-                DS_NCCL_G(api.Recv(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, stream));
+                DS_NCCL_G(api.Recv(s.stage + off[j], (size_t)(pnl[j] * s.g.ntl), ncclDouble, j, (ncclComm_t)nccl, cs));
         }
         --open_groups;
         DS_NCCL(api.GroupEnd());
+        DS_CHECK(comm_leave());
         DS_CHECK(launch_pencil_pack(false, pc, plane, s.g.ntl, s.w0, s.stage, stream));
     }
     return 0;
@@ -746,7 +810,7 @@ static void tri_layout(i64 plane, i64 nt, int world, PencilCuts &pc, std::vector
 }
 
 int Solver::tri_alloc() {
-    const i64 plane = ny * nx;
+    const i64 plane = slabs[0].g.plane;
     for (auto &s : slabs) {
         if (s.tri_send) continue;
         DS_CHECK(use(s));
@@ -761,12 +825,13 @@ int Solver::tri_alloc() {
 
 // back == false: every slab's message for owner j -> owner j (slot of the sending slab); back == true: the way back
 int Solver::tri_exchange(bool back) {
-    const i64 plane = ny * nx;
+    const i64 plane = slabs[0].g.plane;
     PencilCuts pc{};
     std::vector<i64> slab_n;
     tri_layout(plane, nt, world, pc, slab_n);
     auto off = [&](int j) { return 2 * pc.cut[j] + (i64)TRI_EXTRA * j; };                  // in tri_send / tri_brecv
     auto cnt = [&](int j) { return 2 * (pc.cut[j + 1] - pc.cut[j]) + (i64)TRI_EXTRA; };  // message for / from owner j
+    DS_CHECK(comm_enter());
     if (!remote()) {
         // Slabs of one process: every receiver pulls all its messages with ONE launch (peer pointers; P launches and
         // P * P stream waits instead of P * P event-ordered copies, whose host cost grew to 2.8 ms per iteration at
@@ -774,12 +839,12 @@ int Solver::tri_exchange(bool back) {
         // overwrites its message only behind its own next gather, which waits for every receiver of this one.
         const bool gather = pull_default("DOTSOCP_TRI_GATHER");
         if (gather) {
-            FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, s.st));
+            FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, cst(s)));
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
                 GatherMsgs m{};
                 m.n = 0;
                 for (auto &ss : slabs) {    // sender
-                    if (ss.st != sd.st) DS_HIP(ds_stream_wait_event(sd.st, ss.ev_tri, 0));
+                    if (cst(ss) != cst(sd)) DS_HIP(ds_stream_wait_event(cst(sd), ss.ev_tri, 0));
                     const int d = sd.index, q = ss.index;
                     if (!back) {            // slab q's message for owner d
                         m.src[m.n] = ss.tri_send + off(d);
@@ -792,9 +857,9 @@ int Solver::tri_exchange(bool back) {
                     }
                     ++m.n;
                 }
-                DS_CHECK(launch_gather_msgs(m, sd.st));
+                DS_CHECK(launch_gather_msgs(m, cst(sd)));
             }
-            return 0;
+            return comm_leave();
         }
         for (auto &sp : slabs)             // slab p
             for (auto &sj : slabs) {       // owner j
@@ -804,49 +869,78 @@ int Solver::tri_exchange(bool back) {
                 if (back) DS_CHECK(xcopy(sj, a, sp, b, cnt(j)));
                 else DS_CHECK(xcopy(sp, a, sj, b, cnt(j)));
             }
-        return 0;
+        return comm_leave();
     }
+    // one slab per process.  The rank's own part does not travel: k_tri_reduced reads it where k_tri_local wrote it and
+    // k_tri_final reads the answer where k_tri_reduced left it (launch_tri_reduced / _final: `own`)
     Rccl &api = rccl_api();
     Slab &s = slabs[0];
-    {
-        double *a = s.tri_send + off(rank), *b = s.tri_recv + (i64)rank * cnt(rank);
-        if (back) { a = s.tri_bsend + (i64)rank * cnt(rank); b = s.tri_brecv + off(rank); }
-        DS_HIP(ds_memcpy_async(b, a, sizeof(double) * (size_t)cnt(rank), hipMemcpyDeviceToDevice, stream));
-    }
+    const hipStream_t cs = cst(s);
     DS_NCCL(api.GroupStart());
     ++open_groups;
     for (int j = 0; j < world; ++j) {
         if (j == rank) continue;
         if (!back) {
-            DS_NCCL_G(api.Send(s.tri_send + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
-            DS_NCCL_G(api.Recv(s.tri_recv + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL_G(api.Send(s.tri_send + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, cs));
+            DS_NCCL_G(api.Recv(s.tri_recv + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, cs));
         } else {
-            DS_NCCL_G(api.Send(s.tri_bsend + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, stream));
-            DS_NCCL_G(api.Recv(s.tri_brecv + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, stream));
+            DS_NCCL_G(api.Send(s.tri_bsend + (i64)j * cnt(rank), (size_t)cnt(rank), ncclDouble, j, (ncclComm_t)nccl, cs));
+            DS_NCCL_G(api.Recv(s.tri_brecv + off(j), (size_t)cnt(j), ncclDouble, j, (ncclComm_t)nccl, cs));
         }
     }
     --open_groups;
     DS_NCCL(api.GroupEnd());
-    return 0;
+    return comm_leave();
 }
 
-int Solver::poisson_t_tridiag() {
-    const i64 plane = ny * nx;
+// hooks (asynchronous schedule of step(), messages on the second streams): the latency-bound middle of the solve -- local
+// eliminations, interface exchange, reduced systems, interface exchange: two small kernels and two rounds of messages --
+// runs on the SECOND streams while hooks->fill (the last cone chunk) keeps the main streams busy; hooks->behind is called
+// once both have been joined (more messages for the second streams).
+int Solver::poisson_t_tridiag(const PhiHooks *hooks) {
+    const i64 plane = slabs[0].g.plane;
     DS_CHECK(tri_alloc());
     PencilCuts pc{};
     std::vector<i64> slab_n;
     tri_layout(plane, nt, world, pc, slab_n);
     const double kscale = D * D;
-    FOR_SLABS(s) DS_CHECK(launch_tri_local(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.w0, s.tri_send, s.st));
-    prof_begin(PH_TRANSPOSE);
-    DS_CHECK(tri_exchange(false));
-    prof_end(PH_TRANSPOSE);
-    FOR_SLABS(s)
-        DS_CHECK(launch_tri_reduced(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.index, s.l0, s.nl, slab_n.data(), s.tri_recv,
-                                    s.tri_bsend, s.tri_zero, s.st));
-    prof_begin(PH_TRANSPOSE);
-    DS_CHECK(tri_exchange(true));
-    prof_end(PH_TRANSPOSE);
+    const bool async = hooks != nullptr && comm_z;
+    auto own_off = [&](const Slab &s) { return 2 * pc.cut[s.index] + (i64)TRI_EXTRA * s.index; };
+    if (async) {
+        DS_CHECK(comm_fork());
+        comm_async = true;
+    }
+    // (synchronous form: kernels on the main streams, every exchange forks and joins by itself)
+    FOR_SLABS(s) DS_CHECK(launch_tri_local(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.w0, s.tri_send, async ? cst(s) : s.st));
+    int rc = 0;
+    prof_begin(PH_TRANSPOSE, async);
+    rc = tri_exchange(false);
+    prof_end(PH_TRANSPOSE, async);
+    if (rc == 0) {
+        for (auto &s : slabs) {
+            if ((rc = use(s)) != 0) break;
+            const bool own = remote();       // one slab per process: the own message stays where it is (tri_exchange)
+            rc = launch_tri_reduced(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.index, s.l0, s.nl, slab_n.data(), s.tri_recv,
+                                    s.tri_bsend, s.tri_zero, async ? cst(s) : s.st, own ? s.tri_send + own_off(s) : nullptr,
+                                    own ? s.tri_brecv + own_off(s) : nullptr);
+            if (rc != 0) break;
+        }
+    }
+    if (rc == 0) {
+        prof_begin(PH_TRANSPOSE, async);
+        rc = tri_exchange(true);
+        prof_end(PH_TRANSPOSE, async);
+    }
+    comm_async = false;
+    DS_CHECK(rc);
+    if (async) DS_CHECK(comm_mark(&Slab::ev_halo));
+    if (hooks && hooks->fill) {
+        prof_end(PH_POISSON);
+        DS_CHECK(hooks->fill());
+        prof_begin(PH_POISSON);
+    }
+    if (async) DS_CHECK(comm_wait(&Slab::ev_halo));
+    if (hooks && hooks->behind) DS_CHECK(hooks->behind());
     FOR_SLABS(s) DS_CHECK(launch_tri_final(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.tri_brecv, s.w0, s.w1, s.st));
     return 0;
 }
@@ -1061,6 +1155,8 @@ int Solver::flush_alpha() {
 // the q-step stored: A'(w.*q - alpha / f) + c / f = (rhs + r) - r / f.  c is divided in that same small pass.
 int Solver::sigma_scale_folded(double factor) {
     DS_CHECK(flush_alpha());
+    DS_CHECK(ensure_halo());
+    u0_made = false;
     DS_CHECK(push_beta_op(1.0, factor));
     if (multi()) {
         // time slabs: the u0 tail for the right neighbour is formed from alpha in memory before the next q-step runs
@@ -1075,6 +1171,8 @@ int Solver::sigma_scale_folded(double factor) {
 
 int Solver::scale_state(double a_mul, double a_div, double q_div, bool with_c) {
     DS_CHECK(flush_alpha());
+    if (begun) DS_CHECK(ensure_halo());
+    u0_made = false;
     u0_fresh = false;      // q0 / alpha0 change: the u0 tail held by the right neighbour is stale
     rhs_valid = false;     // ... and so is the right-hand side the last q-step left in w0
     if (fused && begun) {
@@ -1167,8 +1265,8 @@ int Solver::begin(const dotsocp_opts *o) {
 // the four steps of one iteration
 // --------------------------------------------------------------------------------------
 // phi = idctn(dctn(rhs) ./ kernel), kernel = D^2 * initialize_FFTkernel  (:96,194); rhs is in w0
-int Solver::poisson_all() {
-    const i64 plane = ny * nx;
+int Solver::poisson_all(const PhiHooks *hooks) {
+    const i64 plane = slabs[0].g.plane;
     const bool tp2 = dct_plan_has_tsolve(devres[0]->pt);
     FOR_SLABS(s) {
         const Grid &g = s.g;
@@ -1178,8 +1276,14 @@ int Solver::poisson_all() {
     bool tri = multi() && tri_tsolve && world <= DS_MAX_WORLD;
     for (auto &s : slabs) tri = tri && s.g.ntl <= TRI_EXTRA;
     if (tri) {
-        DS_CHECK(poisson_t_tridiag());
+        DS_CHECK(poisson_t_tridiag(hooks));
     } else {
+    if (hooks && hooks->fill) {
+        prof_end(PH_POISSON);
+        DS_CHECK(hooks->fill());
+        prof_begin(PH_POISSON);
+    }
+    if (hooks && hooks->behind) DS_CHECK(hooks->behind());
     if (multi()) {       // timed on its own (inside "poisson") so that the scaling runs show what the all-to-alls cost
         prof_begin(PH_TRANSPOSE);
         DS_CHECK(transpose(true));
@@ -1220,12 +1324,13 @@ int Solver::poisson_all() {
     return 0;
 }
 
-int Solver::phase_phi() {
+int Solver::phase_phi(const PhiHooks *hooks) {
     DS_CHECK(ensure_halo());
     if (multi() && !u0_fresh) {      // normally shipped with the q halo at the end of the previous iteration
-        prof_begin(PH_COMM);
+        DS_CHECK(make_u0_tail());
+        prof_begin(PH_COMM, comm_z);
         DS_CHECK(exchange_u0_tail());
-        prof_end(PH_COMM);
+        prof_end(PH_COMM, comm_z);
     }
     prof_begin(PH_RHS);
     if (!rhs_valid) {
@@ -1239,27 +1344,28 @@ int Solver::phase_phi() {
     rhs_valid = false;
     prof_end(PH_RHS);
     prof_begin(PH_POISSON);
-    DS_CHECK(poisson_all());
+    DS_CHECK(poisson_all(hooks));
     prof_end(PH_POISSON);
     return 0;                        // the phi head travels with the adjoint tails (phase_z_tails)
 }
 
-// The cone pass needs q^k and beta only -- not phi^{k+1} -- so it may run on every slab's second stream
-// (on_z) concurrently with the phi step (rhs, Poisson solve and, in time-slab mode, its exchanges).
-int Solver::phase_z(bool on_z, int part) {
+// The cone pass needs q^k and beta only -- not phi^{k+1}.  Time slabs: it runs in chunks of time cells, one launch per
+// chunk in ascending order (the "t + 1" cone entries of a chunk's last cell travel to the next launch through s.carry),
+// and only the last chunk reads the q halo -- step() puts the others in front of the halo's arrival (part 1) and the
+// last one beside the first interface exchange of the Poisson solve (part 2).
+int Solver::phase_z(int part) {
     if (part != 1) DS_CHECK(ensure_halo());     // the last chunk reads the q halo (part 1 never does)
     if (!fused) {
-        prof_begin(PH_PROJ, on_z);
-        FOR_SLABS(s) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, on_z ? s.st_z : s.st));
-        prof_end(PH_PROJ, on_z);
+        prof_begin(PH_PROJ);
+        FOR_SLABS(s) DS_CHECK(launch_cone_proj(s.g, lc, s.q, s.beta, s.z, s.st));
+        prof_end(PH_PROJ);
         return 0;
     }
     const int ph = deferred ? PH_FUSED_B : PH_FUSED_A;
     z_valid = false;          // the fused pass forms z^{k+1} in registers only
     z_prev_ok = false;        // ... and (mode B) overwrites the kept beta^{k-1}
-    if (part != 2) prof_begin(ph, on_z);
+    prof_begin(ph);
     FOR_SLABS(s) {
-        hipStream_t st = on_z ? s.st_z : s.st;
         FusedArgs a{};
         a.q = s.q;
         a.q2 = s.q2;
@@ -1267,20 +1373,28 @@ int Solver::phase_z(bool on_z, int part) {
         a.sy = s.sy;
         a.beta_in = s.beta;
         set_pending(a);
-        const i64 z0 = (part == 2) ? s.fg.chunks - 1 : 0;
-        const i64 zc = (part == 0) ? s.fg.chunks : ((part == 1) ? s.fg.chunks - 1 : 1);
+        const i64 C = s.fg.chunks;
+        const i64 z0 = (part == 2) ? C - 1 : 0;
+        const i64 zc = (part == 0) ? C : ((part == 1) ? C - 1 : 1);
         if (deferred) {
             // beta^k = beta^{k-1} + tau (z^k - BF q^k - d) folded into this iteration's projection
             a.q_old = s.q_old;
             a.beta_out = s.beta2;
-            DS_CHECK(launch_cone_fused(1, s.g, lc, s.fg, a, st, z0, zc));
-            if (part != 1) std::swap(s.beta, s.beta2);
-        } else {
-            DS_CHECK(launch_cone_fused(0, s.g, lc, s.fg, a, st, z0, zc));
         }
+        const int mode = deferred ? 1 : 0;
+        if (s.carry && C > 1) {
+            for (i64 z = z0; z < z0 + zc; ++z) {
+                a.carry_in = (z > 0) ? s.carry : nullptr;
+                a.carry_out = (z + 1 < C) ? s.carry : nullptr;
+                DS_CHECK(launch_cone_fused(mode, s.g, lc, s.fg, a, s.st, z, 1));
+            }
+        } else {
+            DS_CHECK(launch_cone_fused(mode, s.g, lc, s.fg, a, s.st, z0, zc));
+        }
+        if (deferred && part != 1) std::swap(s.beta, s.beta2);
     }
+    prof_end(ph);
     if (part == 1) return 0;
-    prof_end(ph, on_z);
     if (deferred) bpend = 0;          // mode B rewrote beta with the scaling applied
     return 0;
 }
@@ -1290,19 +1404,41 @@ int Solver::phase_z_tails() {
     return fused ? ship_tails() : 0;
 }
 
+// adjoint sums of every slab's last cell for the first edge layer of its right neighbour (kernel, main streams)
+int Solver::make_tails() {
+    if (!multi()) return 0;
+    FOR_SLABS(s)
+        if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.q2, s.sx, s.sy, s.send_bx, s.send_by, s.st));
+    return 0;
+}
+
+int Solver::send_tails() {
+    if (!multi()) return 0;
+    prof_begin(PH_COMM, comm_z);
+    DS_CHECK(group_begin());
+    DS_CHECK(shift(+1, [](Slab &s) { return s.send_bx; }, [](Slab &s) { return s.tail_bx; }, slabs[0].g.bxLayer));
+    DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.tail_by; }, slabs[0].g.byLayer));
+    DS_CHECK(group_end());
+    prof_end(PH_COMM, comm_z);
+    return 0;
+}
+
+// first phi layer of every slab -> halo layer of its left neighbour (forward time difference of the q-step)
+int Solver::send_phi_head() {
+    if (!multi()) return 0;
+    prof_begin(PH_COMM, comm_z);
+    DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, slabs[0].g.plane));
+    prof_end(PH_COMM, comm_z);
+    return 0;
+}
+
 int Solver::ship_tails() {
     if (multi()) {
-        // adjoint sums of every slab's last cell for the first edge layer of its right neighbour
-        prof_begin(PH_COMM);
-        FOR_SLABS(s)
-            if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.q2, s.sx, s.sy, s.send_bx, s.send_by, s.st));
-        DS_CHECK(group_begin());
-        // first phi layer of every slab -> halo layer of its left neighbour (forward time difference of the q-step)
-        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
-        DS_CHECK(shift(+1, [](Slab &s) { return s.send_bx; }, [](Slab &s) { return s.tail_bx; }, slabs[0].g.bxLayer));
-        DS_CHECK(shift(+1, [](Slab &s) { return s.send_by; }, [](Slab &s) { return s.tail_by; }, slabs[0].g.byLayer));
+        DS_CHECK(make_tails());
+        DS_CHECK(group_begin());        // one group: traffic in both directions at once
+        DS_CHECK(send_phi_head());
+        DS_CHECK(send_tails());
         DS_CHECK(group_end());
-        prof_end(PH_COMM);
     }
     return 0;
 }
@@ -1319,9 +1455,9 @@ KktCoef Solver::kkt_coef() const {
 // kkt: the iteration ends with a KKT check and the q-step runs in its KKT variant (one slab: part == 0)
 int Solver::phase_q(int part, bool kkt) {
     if (!(fused && qrhs)) DS_CHECK(flush_alpha());
-    if (part != 1) prof_begin(PH_QSTEP);
+    prof_begin(PH_QSTEP);
     FOR_SLABS(s) {
-        hipStream_t st = (part == 1) ? s.st_z : s.st;
+        hipStream_t st = s.st;
         if (!fused) {
             DS_CHECK(launch_qstep(s.g, lc, s.phi, s.z, s.beta, s.weight, s.tail_bx, s.tail_by, s.q, s.alpha, s.st));
         } else {
@@ -1330,10 +1466,11 @@ int Solver::phase_q(int part, bool kkt) {
                 // ... and the right-hand side of the next phi-step is formed in the same pass (alpha ping-pongs)
                 const i64 C = qstep_rhs_chunks(s.g, s.fg);
                 i64 z0 = 0, zc = C, zs = 1;
-                if (part == 1) { z0 = 1; zc = C - 2; }             // the chunks in the middle
-                else if (part == 2) { zc = 2; zs = C - 1; }        // first and last chunk in one launch
+                if (part == 1) { zc = C - 1; }                     // all but the last chunk
+                else if (part == 2) { z0 = C - 1; zc = 1; }        // the last chunk
                 QStepExtra ex{};
                 ex.apend = apend ? 1 : 0; ex.amul = amul; ex.adiv = adiv;
+                if (multi() && !s.g.last && part != 1) ex.u0_tail = s.send_plane;
                 if (kkt) {
                     const KktCoef k = kkt_coef();
                     ex.partials = kkt_qstep_partials(s.g, s.kw);
@@ -1350,15 +1487,13 @@ int Solver::phase_q(int part, bool kkt) {
             if (part != 1) std::swap(s.q, s.q_old);
         }
     }
-    if (part == 1) return 0;
-    if (fused && qrhs) apend = false;        // the q-step wrote the scaled alpha into the ping-pong partner
     prof_end(PH_QSTEP);
-    if (part == 2) {                                                    // the middle chunks (second streams)
-        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.ev_join, 0));
-    }
+    if (part == 1) return 0;
+    u0_made = multi() && fused && qrhs;
+    if (fused && qrhs) apend = false;        // the q-step wrote the scaled alpha into the ping-pong partner
     rhs_valid = fused && qrhs;
     // the halo exchange waits for the next consumer: the next step() runs it beside the first cone chunks
-    if (multi() && fused && overlap && cone_split_enabled()) halo_pending = true;
+    if (multi() && fused && comm_z && cone_split_enabled()) halo_pending = true;
     else DS_CHECK(exchange_q_halo(true));
     return 0;
 }
@@ -1468,7 +1603,8 @@ int Solver::kkt_sums(double *S, bool folded) {
         rest |= 2;
     }
     if (multi()) {
-        const i64 plane = ny * nx;
+        const i64 plane = slabs[0].g.plane;
+        u0_made = false;                      // launch_kkt_tail reuses send_plane
         FOR_SLABS(s)
             if (!s.g.last)
                 DS_CHECK(launch_kkt_tail(s.g, s.alpha, s.beta, s.weight, s.send_plane, s.send_plane2, s.send_bx, s.send_by,
@@ -1512,11 +1648,14 @@ int Solver::reduce_sums(double *S) {
         // sum the partial sums over the ranks; slot S_COUNT carries the wall clock (max via a second reduce)
         Rccl &api = rccl_api();
         Slab &s = slabs[0];
-        DS_NCCL(api.AllReduce(s.kw.sums, d_red, S_COUNT, ncclDouble, ncclSum, (ncclComm_t)nccl, stream));
+        DS_CHECK(comm_enter());
+        const hipStream_t cs = cst(s);
+        DS_NCCL(api.AllReduce(s.kw.sums, d_red, S_COUNT, ncclDouble, ncclSum, (ncclComm_t)nccl, cs));
         h_sums[S_COUNT] = S[S_COUNT];
-        DS_HIP(ds_memcpy_async(d_red + S_COUNT, h_sums + S_COUNT, sizeof(double), hipMemcpyHostToDevice, stream));
-        DS_NCCL(api.AllReduce(d_red + S_COUNT, d_red + S_COUNT, 1, ncclDouble, ncclMax, (ncclComm_t)nccl, stream));
-        DS_HIP(ds_memcpy_async(h_sums, d_red, sizeof(double) * (S_COUNT + 1), hipMemcpyDeviceToHost, stream));
+        DS_HIP(ds_memcpy_async(d_red + S_COUNT, h_sums + S_COUNT, sizeof(double), hipMemcpyHostToDevice, cs));
+        DS_NCCL(api.AllReduce(d_red + S_COUNT, d_red + S_COUNT, 1, ncclDouble, ncclMax, (ncclComm_t)nccl, cs));
+        DS_HIP(ds_memcpy_async(h_sums, d_red, sizeof(double) * (S_COUNT + 1), hipMemcpyDeviceToHost, cs));
+        DS_CHECK(comm_leave());
         DS_HIP(ds_stream_synchronize(stream));
         for (int i = 0; i <= S_COUNT; ++i) S[i] = h_sums[i];
     }
@@ -1717,51 +1856,60 @@ int Solver::step(bool *brk) {
     const bool kkt_due = opts.ifCheckStepByStep || adjustSigmaYes || it == opts.maxit;
     // fused dataflow: the q-step of a checking iteration accumulates its share of the KKT sums itself
     const bool fold = kkt_due && kkt_fold && fused && qrhs;
-    bool split = overlap && fused && halo_pending;
+    // Time slabs, messages on the second streams (solver.h: comm_z): kernels on the main streams in an order that leaves
+    // every message time to travel while kernels that do not need it run.
+    const bool inter = comm_z && multi() && fused && qrhs;
+    bool split = inter && cone_split_enabled();
     for (auto &s : slabs) split = split && s.fg.chunks >= 2;
-    if (split) {
-        // as below, and the q halo / u0 tail of the last q-step travel (main stream) while stream_z works on the
-        // cone chunks that do not read the halo; only the last chunk of every slab waits for it
-        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_fork, s.st));
-        DS_CHECK(ensure_halo());
-        FOR_SLABS(s) {
-            DS_HIP(ds_event_record(s.ev_halo, s.st));
-            DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
+    bool split_q = inter && cone_split_enabled();
+    for (auto &s : slabs) split_q = split_q && qstep_rhs_chunks(s.g, s.fg) >= 2;
+    // an exchange issued on the second streams without the join: fork, messages, mark
+    auto async_comm = [&](const std::function<int()> &fn, hipEvent_t Slab::*ev) -> int {
+        DS_CHECK(comm_fork());
+        comm_async = true;
+        const int rc = fn();
+        comm_async = false;
+        DS_CHECK(rc);
+        return comm_mark(ev);
+    };
+    if (inter) {
+        // [E2 + E1] the q halo and the u0 tail of the last q-step travel while the cone chunks in front of the last one
+        // -- which alone reads the halo -- run
+        const bool pend = halo_pending;
+        if (pend) {
+            DS_CHECK(make_u0_tail());
+            DS_CHECK(async_comm([&]() { return ensure_halo(); }, &Slab::ev_halo));
         }
-        DS_CHECK(phase_z(true, 1));
-        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st_z, s.ev_halo, 0));
-        DS_CHECK(phase_z(true, 2));
-        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_join, s.st_z));
-        DS_CHECK(phase_phi());
-        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.ev_join, 0));
-    } else if (overlap) {
-        // fork: cone pass on stream_z beside the phi step on the main stream, join before the q-step
-        DS_CHECK(ensure_halo());
-        DS_CHECK(fork_z());
-        DS_CHECK(phase_z(true));
-        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_join, s.st_z));
-        DS_CHECK(phase_phi());
-        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.ev_join, 0));
+        if (split) DS_CHECK(phase_z(1));
+        if (pend) DS_CHECK(comm_wait(&Slab::ev_halo));
+        if (!split) DS_CHECK(phase_z(0));
+        // The phi-step.  The last cone chunk (and the finalising of its adjoint tails) runs while the second streams carry
+        // the latency-bound middle of the Poisson solve (poisson_t_tridiag); the tails [E4] leave right behind that and
+        // travel beside the rest of the solve and the front of the q-step
+        PhiHooks hooks;
+        hooks.fill = [&]() -> int {
+            if (split) DS_CHECK(phase_z(2));
+            return make_tails();
+        };
+        hooks.behind = [&]() -> int { return async_comm([&]() { return send_tails(); }, &Slab::ev_join); };
+        DS_CHECK(phase_phi(&hooks));
     } else {
         DS_CHECK(phase_phi());
-        DS_CHECK(phase_z(false));
+        DS_CHECK(phase_z(0));
     }
-    bool split_q = overlap && fused && qrhs && multi() && cone_split_enabled();
-    for (auto &s : slabs) split_q = split_q && qstep_rhs_chunks(s.g, s.fg) >= 3;
     if (fold) {
         // every region of partial sums is cleared before the q-step writes region 0; kkt_sums() then only adds the cell,
         // border and (time slabs) first-layer launches
         FOR_SLABS(s) DS_HIP(ds_memset_async(s.kw.partials, 0, sizeof(double) * s.kw.maxBlocks * S_COUNT, s.st));
     }
-    if (split_q) {
-        // the chunks of the q-step that need neither neighbour run on stream_z while the phi head and the adjoint
-        // tails travel on the main stream; the first and the last chunk follow the exchange
-        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_fork, s.st));    // phi^{k+1} and the cone pass are complete
-        DS_CHECK(phase_z_tails());                               // enqueued first: the exchange gets its CUs at once
-        FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
-        DS_CHECK(phase_q(1, fold));
-        FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_join, s.st_z));
-        DS_CHECK(phase_q(2, fold));
+    if (inter) {
+        // [E3] the phi head travels (behind the tails) while every chunk of the q-step but the last -- the only reader of
+        // the phi halo -- runs; the tails (read by the first chunk) have had the second half of the phi-step to arrive
+        DS_CHECK(async_comm([&]() { return send_phi_head(); }, &Slab::ev_halo));
+        DS_CHECK(comm_wait(&Slab::ev_join));
+        if (split_q) DS_CHECK(phase_q(1, fold));
+        DS_CHECK(comm_wait(&Slab::ev_halo));
+        DS_CHECK(phase_q(split_q ? 2 : 0, fold));
     } else {
         DS_CHECK(phase_z_tails());
         DS_CHECK(phase_q(0, fold));

@@ -373,7 +373,7 @@ __device__ __forceinline__ double fbbf_edge(const LoopCoef &c, double e, bool tb
 struct QRhsArgs {
     const double *phi, *q2v, *sx, *sy, *weight, *tail_bx, *tail_by, *cvec, *alpha_in;
     double *q_out, *alpha_out, *rhs;
-    double *u0_tail;   // time slabs, VAR 1 / 2 (optional): raw u0 = w.*q0^+ - alpha0^+ of the last owned cell layer, for the right slab's rhs
+    double *u0_tail;   // time slabs, VAR 0 - 2 (optional): raw u0 = w.*q0^+ - alpha0^+ of the last owned cell layer, for the right slab's rhs
     i64 TC, z0, zstride;   // layers per chunk; this launch runs the chunks z0 + blockIdx.z * zstride
     // VAR 2 (acc-ADMM, Halpern step folded in): q_out receives the raw q^+ (the cone pass needs it), the
     // extrapolated q goes to q_state in place and the extrapolated alpha to alpha_out
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(TILE_Y *QTX, (QTX > TILE_X && !WEIGHTED ? 4 : 
         // ---------------- stores ----------------
         if (hasCell) {
             put(node, q0n, a0n, ain0);
-            if ((VAR == 1 || VAR == 2) && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.py * x] = u0;
+            if (VAR != 3 && a.u0_tail && tl == g.ncl - 1 && !g.last) a.u0_tail[y + g.py * x] = u0;
         }
         if (hasBx) put(eX, qXn, aXn, ainX);
         if (hasBy) put(eY, qYn, aYn, ainY);
@@ -766,6 +766,7 @@ int launch_qstep_rhs(const Grid &g, const LoopCoef &c, const FusedGeom &fg, cons
         a.ap = APend{ex->apend, ex->amul, ex->adiv};
         a.partials = ex->partials;
         a.resid = ex->resid;
+        a.u0_tail = ex->u0_tail;
         a.kappa = ex->kappa;
         a.dsD = ex->dsD;
     }
@@ -820,8 +821,11 @@ i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TCout) {
     // a slab of a time-slab decomposition: at least four chunks, so that the two in the middle -- which need neither
     // neighbour -- can run while the phi head and the adjoint tails travel (Solver::step)
     if (!(g.first && g.last) && cone_split_enabled() && g.ntl >= 12) {
-        const i64 quarter = (g.ntl + 3) / 4;
-        if (TC > quarter) TC = quarter < 4 ? 4 : quarter;
+        // ... the LAST chunk -- the only one that waits for the phi head of the right neighbour -- about a quarter of the
+        // slab, the chunks in front of it up to eight layers each (16 layers: 6 + 6 + 4)
+        const i64 tail = (g.ntl / 4 < 4) ? 4 : g.ntl / 4;
+        const i64 body = g.ntl - tail, nb = (body + 7) / 8;
+        TC = (body + nb - 1) / nb;
     }
     if (TC > g.ntl) TC = g.ntl;
     if (TC < 1) TC = 1;

@@ -85,6 +85,11 @@ struct TriReduced {
     i64 l0, nl;               // owned modes [l0, l0 + nl)
     i64 nt;
     i64 slab_n[DS_MAX_WORLD]; // time nodes of every slab
+    // one slab per process: the message of slab `own` (this rank's) does not travel -- it is read where k_tri_local wrote it
+    // (own_recv, inside tri_send) and its answer is written where k_tri_final reads it (own_back, inside tri_brecv)
+    int own;                  // -1: every message lies in recv / back
+    const double *own_recv;
+    double *own_back;
 };
 
 // PMAX: compile-time bound on the number of slabs -- the four sweep arrays are then fully unrolled and live in registers
@@ -96,13 +101,15 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
     if (i >= q.nl) return;
     const i64 m = q.l0 + i;
     const i64 stride = 2 * q.nl + TRI_EXTRA;      // one message per slab
+    auto msg_in = [&](int p) { return (p == q.own) ? q.own_recv : recv + p * stride; };
+    auto msg_out = [&](int p) { return (p == q.own) ? q.own_back : back + p * stride; };
     if (m == 0) {
         // T x = g - mean(g) by recurrence from x_0 = 0, then zero mean, plus beta * mean(g)
         double sum = 0.0;
         i64 tg = 0;
         for (int p = 0; p < q.P; ++p)
             for (i64 t = 0; t < q.slab_n[p]; ++t, ++tg) {
-                const double v = recv[p * stride + 2 * q.nl + t];
+                const double v = msg_in(p)[2 * q.nl + t];
                 zero_work[tg] = v;
                 sum += v;
             }
@@ -119,8 +126,8 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
         const double shift = g.beta * gbar - acc / (double)q.nt;
         tg = 0;
         for (int p = 0; p < q.P; ++p)
-            for (i64 t = 0; t < q.slab_n[p]; ++t, ++tg) back[p * stride + 2 * q.nl + t] = zero_work[tg] + shift;
-        for (int p = 0; p < q.P; ++p) { back[p * stride + i] = 0.0; back[p * stride + q.nl + i] = 0.0; }
+            for (i64 t = 0; t < q.slab_n[p]; ++t, ++tg) msg_out(p)[2 * q.nl + t] = zero_work[tg] + shift;
+        for (int p = 0; p < q.P; ++p) { msg_out(p)[i] = 0.0; msg_out(p)[q.nl + i] = 0.0; }
         return;
     }
     const double ap = tri_aprime(g, m);
@@ -148,7 +155,8 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
         double vf = 1.0 / piv, wf = prod / piv;
         if (first) vf = vl = 0.0;                 // no left / right neighbour
         if (last) wf = wl = 0.0;
-        const double Gf = recv[p * stride + i], Gl = recv[p * stride + q.nl + i];
+        const double *mi = msg_in(p);
+        const double Gf = mi[i], Gl = mi[q.nl + i];
         // unknowns F_p (first value of slab p), L_p (last value):  F_p = Gf + vf L_{p-1} + wf F_{p+1},  L_p = Gl + vl L_{p-1} + wl F_{p+1}
         // sweep: L_{p-1} = al + ga F_p  ->  F_p = A + B F_{p+1},  L_p = al' + ga' F_{p+1}
         if (p == 0) {
@@ -168,8 +176,9 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
         if (p >= q.P) continue;
         const double F = A[p] + B[p] * Fnext;
         const double Lprev = (p > 0) ? al[p - 1] + ga[p - 1] * F : 0.0;
-        back[p * stride + i] = Lprev;
-        back[p * stride + q.nl + i] = Fnext;
+        double *mo = msg_out(p);
+        mo[i] = Lprev;
+        mo[q.nl + i] = Fnext;
         Fnext = F;
     }
 }
@@ -339,11 +348,13 @@ int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, con
 
 int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                        int rank, i64 l0, i64 nl, const i64 *slab_n, const double *recv, double *back, double *zero_work,
-                       hipStream_t st) {
+                       hipStream_t st, const double *own_recv, double *own_back) {
     if (nl <= 0) return 0;
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
     TriReduced q{};
     q.P = pc.world; q.rank = rank; q.l0 = l0; q.nl = nl; q.nt = nt;
+    q.own = (own_recv && own_back) ? rank : -1;
+    q.own_recv = own_recv; q.own_back = own_back;
     for (int p = 0; p < pc.world; ++p) q.slab_n[p] = slab_n[p];
     const dim3 grid((unsigned)((nl + 127) / 128));
     if (pc.world <= 4) DS_KLAUNCH(k_tri_reduced<4>, grid, dim3(128), 0, st, t, q, recv, back, zero_work);

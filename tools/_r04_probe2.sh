@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-4 probe 2: the interleaved time-slab schedule (messages on the second streams) -- timing, timeline, slab suites
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+O=gpurun_out/p2
+mkdir -p $O
+python bench.py --no-cpu-baseline --steps 100 --warmup 20 > $O/full.json 2>$O/full.err || exit 1
+python bench.py --no-cpu-baseline --rank-share 8 > $O/share8.json 2>$O/share8.err || exit 1
+DOTSOCP_OVERLAP=0 python bench.py --no-cpu-baseline --rank-share 8 > $O/share8_nooverlap.json 2>&1
+DOTSOCP_SPLIT_CONE=0 python bench.py --no-cpu-baseline --rank-share 8 > $O/share8_nosplit.json 2>&1
+python bench.py --no-cpu-baseline --rank-share 4 > $O/share4.json 2>&1
+python bench.py --no-cpu-baseline --rank-share 2 > $O/share2.json 2>&1
+python bench.py --no-cpu-baseline --nslabs 8 --steps 100 > $O/nslabs8.json 2>&1
+python bench.py --no-cpu-baseline --nslabs 2 --steps 100 > $O/nslabs2.json 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --rank-share 8 --steps 40 --warmup 10 > $GRAFT_REPO_ROOT/$O/share8_traced.json 2>/dev/null)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/ns2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --nslabs 2 --steps 40 --warmup 10 > $GRAFT_REPO_ROOT/$O/nslabs2_traced.json 2>/dev/null)
+timeout -k 10 900 python -m pytest tests/test_gpu_solver.py tests/test_gpu_multidevice.py tests/test_gpu_multiprocess.py tests/test_gpu_slab_stress.py tests/test_gpu_config4.py tests/test_gpu_palm.py tests/test_gpu_accadmm.py -x -q -m gpu > $O/suite.log 2>&1
+tail -5 $O/suite.log
