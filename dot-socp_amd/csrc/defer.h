@@ -21,9 +21,11 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -42,8 +44,10 @@ struct DeferOp {
     unsigned long long gen = 0;            // record: its generation
 };
 
+struct DeferCtx;
 struct DeferWorker {
     static constexpr unsigned RING = 8192;
+    DeferCtx *ctx = nullptr;
     std::vector<DeferOp> ring;
     std::atomic<unsigned long long> head{0}, tail{0};   // head: recorded, tail: executed
     std::atomic<bool> stop{false};
@@ -58,6 +62,10 @@ struct DeferCtx {
     std::map<hipStream_t, int> stream_worker;           // streams of the slabs -> worker index
     std::map<hipEvent_t, std::unique_ptr<DeferEvent>> events;
     bool active = false;                                // between begin() and end(): closures are recorded
+    // outside run() the workers sleep on this condition (no polling while a context sits idle)
+    std::mutex park_mu;
+    std::condition_variable park_cv;
+    std::atomic<bool> awake{false};
 
     ~DeferCtx();
     int add_worker(int device);                         // returns its index

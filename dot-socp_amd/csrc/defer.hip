@@ -27,6 +27,13 @@ static void worker_main(DeferWorker *w) {
         const unsigned long long t = w->tail.load(std::memory_order_relaxed);
         if (t == w->head.load(std::memory_order_acquire)) {
             if (w->stop.load(std::memory_order_acquire)) return;
+            if (!w->ctx->awake.load(std::memory_order_acquire)) {
+                // the layer is off (outside Solver::run()): sleep until begin() or the destructor says otherwise
+                std::unique_lock<std::mutex> lk(w->ctx->park_mu);
+                w->ctx->park_cv.wait(lk, [&]() { return w->ctx->awake.load(std::memory_order_acquire) || w->stop.load(std::memory_order_acquire); });
+                idle = 0;
+                continue;
+            }
             cpu_relax(idle);
             continue;
         }
@@ -53,16 +60,20 @@ static void worker_main(DeferWorker *w) {
 int DeferCtx::add_worker(int device) {
     std::unique_ptr<DeferWorker> w(new DeferWorker());
     w->device = device;
+    w->ctx = this;
     w->th = std::thread(worker_main, w.get());
     workers.push_back(std::move(w));
     return (int)workers.size() - 1;
 }
 
 DeferCtx::~DeferCtx() {
-    for (auto &w : workers) {
-        w->stop.store(true, std::memory_order_release);
-        if (w->th.joinable()) w->th.join();
+    for (auto &w : workers) w->stop.store(true, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(park_mu);
     }
+    park_cv.notify_all();
+    for (auto &w : workers)
+        if (w->th.joinable()) w->th.join();
 }
 
 void DeferCtx::push(DeferWorker *w, DeferOp &&op) {
@@ -83,6 +94,11 @@ void DeferCtx::begin() {
     }
     for (auto &w : workers) w->first_error.store(0);
     active = true;
+    {
+        std::lock_guard<std::mutex> lk(park_mu);
+        awake.store(true, std::memory_order_release);
+    }
+    park_cv.notify_all();
 }
 
 int DeferCtx::drain_all() {
@@ -106,6 +122,7 @@ int DeferCtx::drain(hipStream_t st) {
 int DeferCtx::end() {
     const int err = drain_all();
     active = false;
+    awake.store(false, std::memory_order_release);      // the workers find their rings empty and park
     return err;
 }
 

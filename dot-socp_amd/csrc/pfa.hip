@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
     double *dp = dst + row * g.drow + y0 + 2 * r;
     double2 *mine = tile + r * N;
     // VEC: every pair starts on an even element and -- when the row has an odd number of lines -- its pitch leaves room
-    // for one more element, so the last pair of a row is fetched and stored as 16 bytes too; what comes in from the pad
-    // is replaced by zero (the pad receives the rounding-level transform of that zero line and is never used as data)
+    // for one more element, so the last pair of a row is fetched as 16 bytes too; what comes in from the pad is replaced by
+    // zero, and only the valid half of that pair is stored (pad entries are zero and are never written: common.h)
     auto ld2 = [&](i64 off) -> double2 {
         if (VEC) {
             double2 v = okA ? *(const double2 *)(sp + off) : make_double2(0.0, 0.0);
@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(T, (PF::N > 1000 ? 4 : 1)) k_pfa_strided(const
     };
     auto st2 = [&](i64 off, double a, double b) {
         if (VEC) {
-            if (okA) *(double2 *)(dp + off) = make_double2(a, b);
+            if (okB) *(double2 *)(dp + off) = make_double2(a, b);
+            else if (okA) dp[off] = a;
         } else {
             if (okA) dp[off] = a;
             if (okB) dp[off + 1] = b;

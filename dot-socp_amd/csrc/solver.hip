@@ -20,7 +20,7 @@ namespace dotsocp {
 
 thread_local std::string g_last_error;
 
-static int make_eig_table(double **dev, i64 n);
+static int make_eig_table(double **dev, i64 n, i64 len = 0);
 
 void set_error(const char *fmt, ...) {
     char buf[1024];
@@ -120,9 +120,11 @@ int Solver::xcopy2d(Slab &from, const double *src, size_t spitch, Slab &to, doub
 }
 
 // ---- communication on the second streams (solver.h: comm_z) ----
+// (slabs that share a pair of streams -- dotsocp_create(.., nslabs) -- are served by the first of them)
 int Solver::comm_fork() {
     if (!comm_z) return 0;
     FOR_SLABS(s) {
+        if (&s != &slabs[0] && s.st == slabs[0].st) continue;
         DS_HIP(ds_event_record(s.ev_fork, s.st));
         DS_HIP(ds_stream_wait_event(s.st_z, s.ev_fork, 0));
     }
@@ -131,13 +133,19 @@ int Solver::comm_fork() {
 
 int Solver::comm_mark(hipEvent_t Slab::*ev) {
     if (!comm_z) return 0;
-    FOR_SLABS(s) DS_HIP(ds_event_record(s.*ev, s.st_z));
+    FOR_SLABS(s) {
+        if (&s != &slabs[0] && s.st == slabs[0].st) continue;
+        DS_HIP(ds_event_record(s.*ev, s.st_z));
+    }
     return 0;
 }
 
 int Solver::comm_wait(hipEvent_t Slab::*ev) {
     if (!comm_z) return 0;
-    FOR_SLABS(s) DS_HIP(ds_stream_wait_event(s.st, s.*ev, 0));
+    FOR_SLABS(s) {
+        if (&s != &slabs[0] && s.st == slabs[0].st) continue;
+        DS_HIP(ds_stream_wait_event(s.st, s.*ev, 0));
+    }
     return 0;
 }
 
@@ -165,7 +173,8 @@ DevRes *Solver::res_for(int dev) {
     r->py = dct_plan_create(ny);
     r->px = dct_plan_create(nx);
     r->pt = dct_plan_create(nt);
-    if (!r->py || !r->px || !r->pt || make_eig_table(&r->cy, ny) != 0 || make_eig_table(&r->cx, nx) != 0 ||
+    // (cy as long as a pitched row: the t-solves of a time-slab context treat the pad entries of a row as modes of their own)
+    if (!r->py || !r->px || !r->pt || make_eig_table(&r->cy, ny, row_pitch()) != 0 || make_eig_table(&r->cx, nx) != 0 ||
         make_eig_table(&r->ct, nt) != 0) {
         set_error("DCT plan allocation failed on device %d", dev);
         dct_plan_destroy(r->py); dct_plan_destroy(r->px); dct_plan_destroy(r->pt);
@@ -242,13 +251,16 @@ Solver::~Solver() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-static int make_eig_table(double **dev, i64 n) {
-    // (2 (n-1)^2) (1 - cos(pi k / n))   -- initialize_FFTkernel.m:6-8
-    std::vector<double> t((size_t)n);
+static int make_eig_table(double **dev, i64 n, i64 len) {
+    // (2 (n-1)^2) (1 - cos(pi k / n))   -- initialize_FFTkernel.m:6-8; entries n .. len-1 (pads of a pitched row, whose data
+    // are zeros) repeat the last one: any positive number keeps their systems regular
+    if (len < n) len = n;
+    std::vector<double> t((size_t)len);
     const double pi = 3.14159265358979323846;
     for (i64 k = 0; k < n; ++k) t[k] = (2.0 * (double)(n - 1) * (double)(n - 1)) * (1.0 - cos(pi * (double)k / (double)n));
-    DS_CHECK(dmalloc(dev, n));
-    DS_HIP(hipMemcpy(*dev, t.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    for (i64 k = n; k < len; ++k) t[k] = (n > 1) ? t[n - 1] : 1.0;
+    DS_CHECK(dmalloc(dev, len));
+    DS_HIP(hipMemcpy(*dev, t.data(), sizeof(double) * len, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -344,7 +356,7 @@ i64 Solver::column_pad() const {
 
 i64 Solver::row_pitch() const {
     static const bool on = !(getenv("DOTSOCP_PITCH") && atoi(getenv("DOTSOCP_PITCH")) == 0);
-    if (!on || world != 1 || ny <= 16) return ny;
+    if (!on || ny <= 16) return ny;
     if (ny % 16 == 0) {
         // Rows whose length in bytes is a multiple of 2 KB: the x lines of the Poisson solve (one 64-byte piece per row, rows a
         // power of two apart) keep hitting the same DRAM banks -- with rows 128 bytes longer the x passes of the pipelined DCT
@@ -364,14 +376,17 @@ int Solver::alloc_slabs(int first, int count) {
     comm_depth = 0;
     comm_async = false;
     slabs.resize(count);
-    const i64 plane = ny * nx;
+    const i64 plane = row_pitch() * nx;          // doubles per layer as stored (Grid::plane)
     for (int r = 0; r < count; ++r) {
         Slab &s = slabs[r];
         s.index = first + r;
         // placement: dotsocp_create_multi deals the slabs round-robin over the visible devices, starting at `device`
         s.dev = (multi_device && !remote()) ? (device + r) % ndev_visible : device;
         DS_CHECK(use(s));
-        if (r == 0) {
+        // dotsocp_create(.., nslabs): all slabs on ONE device share its pair of streams -- their kernels would only compete
+        // for the same HBM (8 slabs of 1024 x 1024 x 16 on concurrent streams: 15.8 ms per iteration, one after the other
+        // 8 x 1.63); dotsocp_create_multi gives every slab its own pair, whichever device it lands on
+        if (r == 0 || !multi_device) {
             s.st = stream; s.st_z = stream_z;
             s.ev_fork = ev_fork; s.ev_join = ev_join; s.ev_halo = ev_halo;
         } else {
@@ -463,15 +478,14 @@ int Solver::alloc_slabs(int first, int count) {
                 if (e != hipErrorPeerAccessAlreadyEnabled) peer_ok = false;
             }
         }
-    // several slabs in this process: one issuing thread per slab (defer.h).  Default: on when the slabs live on DIFFERENT
-    // devices (what a single MATLAB process with opts.ngpu drives: every device has its own submission queue), off when
-    // they share one -- measured there, 8 slabs: 1.26 vs 1.06-1.17 ms per iteration on a 64^3 grid (the threads contend
-    // for the one device's queue and add hand-off latency), 14.1 vs 14.9 ms at 1024 x 1024 x 128.
-    // DOTSOCP_HOST_THREADS=0 / 1 overrides
+    // several slabs with their own streams in this process (dotsocp_create_multi): one issuing thread per slab (defer.h) --
+    // OPT-IN (DOTSOCP_HOST_THREADS=1) until a box with several devices has shown both bit-equal results and a gain: the one
+    // configuration that could be measured, all slabs on one device, is slower with the threads (8 slabs on 64^3: 1.26 vs
+    // 1.06-1.17 ms per iteration -- they contend for the one submission queue and add hand-off latency)
     {
         const char *e = getenv("DOTSOCP_HOST_THREADS");
-        const bool want = e ? (atoi(e) != 0) : (multi_device && cross_device);
-        if (want && count > 1 && !remote()) {
+        const bool want = e && atoi(e) != 0;
+        if (want && count > 1 && !remote() && multi_device) {
             defer.reset(new DeferCtx());
             for (auto &s : slabs) {
                 const int w = defer->add_worker(s.dev);
@@ -626,6 +640,9 @@ int Solver::flush_msgs() {
         if (m.count > 0) { sends[m.from] = 1; gets[m.to] = 1; }
     for (size_t i = 0; i < P; ++i)
         if (sends[i]) {
+            bool other = false;
+            for (const Msg &m : msgs) other = other || (m.from == (int)i && m.count > 0 && cst(slabs[m.to]) != cst(slabs[i]));
+            if (!other) continue;
             DS_CHECK(use(slabs[i]));
             DS_HIP(ds_event_record(slabs[i].ev_msg, cst(slabs[i])));
         }
@@ -650,7 +667,9 @@ int Solver::flush_msgs() {
             ++g.n;
         }
         DS_CHECK(launch_gather_msgs(g, cst(to)));
-        DS_HIP(ds_event_record(to.ev_got, cst(to)));
+        bool other = false;
+        for (const Msg &m : msgs) other = other || (m.to == (int)t && m.count > 0 && cst(slabs[m.from]) != cst(to));
+        if (other) DS_HIP(ds_event_record(to.ev_got, cst(to)));
     }
     for (size_t f = 0; f < P; ++f) {
         if (!sends[f]) continue;
@@ -712,7 +731,7 @@ int Solver::ensure_halo() {
 
 // slabs [y][x][t_local] <-> pencils [columns l0..l0+nl)[all t]; data in w0 resp. pencil
 int Solver::transpose(bool forward) {
-    const i64 plane = ny * nx;
+    const i64 plane = slabs[0].g.plane;
     if (!remote()) {
         for (auto &s : slabs)
             for (auto &p : slabs) {
@@ -839,7 +858,9 @@ int Solver::tri_exchange(bool back) {
         // overwrites its message only behind its own next gather, which waits for every receiver of this one.
         const bool gather = pull_default("DOTSOCP_TRI_GATHER");
         if (gather) {
-            FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, cst(s)));
+            bool one = true;
+            for (auto &s : slabs) one = one && cst(s) == cst(slabs[0]);
+            if (!one) FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, cst(s)));
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
                 GatherMsgs m{};
                 m.n = 0;
@@ -1303,10 +1324,10 @@ int Solver::poisson_all(const PhiHooks *hooks) {
                 DS_CHECK(launch_dct_axis(s.res->pt, p2, p, g.ny, g.nx, nt, 2, 1, s.st, g.py));
             }
         } else if (tp2) {
-            DS_CHECK(launch_dct_t_solve(s.res->pt, p, p, ny, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
+            DS_CHECK(launch_dct_t_solve(s.res->pt, p, p, s.g.py, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
         } else {
             DS_CHECK(launch_dct_axis(s.res->pt, p, p2, s.nl, 1, nt, 2, 0, s.st));
-            DS_CHECK(launch_spectral_divide_pencil(p2, ny, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
+            DS_CHECK(launch_spectral_divide_pencil(p2, s.g.py, plane, s.l0, s.nl, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st));
             DS_CHECK(launch_dct_axis(s.res->pt, p2, p, s.nl, 1, nt, 2, 1, s.st));
         }
     }

@@ -30,7 +30,7 @@ int Solver::acc_alloc() {
             fused_geometry(g, s.fg);
             DS_CHECK(dzalloc(&s.q_old, g.NqAlloc, s.st));
             DS_CHECK(dzalloc(&s.q2, g.NqAlloc, s.st));
-            DS_CHECK(dmalloc(&s.beta2, 10 * g.Nc));
+            DS_CHECK(dzalloc(&s.beta2, 10 * g.Nc, s.st));       // pads of rows and columns stay zero (common.h)
             DS_CHECK(dzalloc(&s.sx, s.fg.sx_len, s.st));
             DS_CHECK(dzalloc(&s.sy, s.fg.sy_len, s.st));
             DS_CHECK(dzalloc(&s.alpha2, g.NqAlloc, s.st));
@@ -115,7 +115,7 @@ int Solver::acc_rescale_block() {
             // the sums are taken at the extrapolated state, whose phi / q halos nobody maintains (the q-step folds the
             // extrapolation of q over owned entries only, phi is extrapolated over owned nodes)
             prof_begin(PH_COMM);
-            DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
+            DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, slabs[0].g.plane));
             prof_end(PH_COMM);
             DS_CHECK(exchange_q_halo(false));
         }
@@ -222,7 +222,7 @@ int Solver::acc_step(bool *brk) {
         prof_begin(PH_COMM);
         DS_CHECK(group_begin());
         DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
-        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, slabs[0].g.plane));
         DS_CHECK(group_end());
         FOR_SLABS(s)
             if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, s.st));
@@ -273,7 +273,7 @@ int Solver::acc_step(bool *brk) {
     if (kkt_due) {
         if (multi()) {     // A phi^+ of a slab's last cell layer reads the right neighbour's first phi^+ layer
             prof_begin(PH_COMM);
-            DS_CHECK(shift(-1, [](Slab &s) { return s.phi_p; }, [](Slab &s) { return s.phi_p + s.g.plane * s.g.ntl; }, ny * nx));
+            DS_CHECK(shift(-1, [](Slab &s) { return s.phi_p; }, [](Slab &s) { return s.phi_p + s.g.plane * s.g.ntl; }, slabs[0].g.plane));
             prof_end(PH_COMM);
         }
         acc_swap_state();

@@ -40,7 +40,7 @@ int Solver::palm_begin() {
     // :136-138  tmp_q = A phi; z = BF tmp_q + d (boundary slots keep their uploaded values, like mexBFd)
     if (multi()) {     // the forward time difference of a slab's last cell layer reads the right neighbour's first phi layer
         prof_begin(PH_COMM);
-        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, ny * nx));
+        DS_CHECK(shift(-1, [](Slab &s) { return s.phi; }, [](Slab &s) { return s.phi + s.g.plane * s.g.ntl; }, slabs[0].g.plane));
         prof_end(PH_COMM);
     }
     FOR_SLABS(s) DS_CHECK(launch_grad(s.g, lc, s.phi, s.q2, s.st));
@@ -117,7 +117,7 @@ int Solver::palm_step(bool *brk) {
             if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q_old, s.alpha, nullptr, s.send_plane, s.st));
         DS_CHECK(group_begin());
         DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
-        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, ny * nx));
+        DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, slabs[0].g.plane));
         DS_CHECK(group_end());
         FOR_SLABS(s)
             if (!s.g.first) DS_CHECK(launch_rhs_fixup(s.g, lc, s.u0_prev, s.w0, s.st));

@@ -23,7 +23,7 @@
 namespace dotsocp {
 
 struct TriGeom {
-    i64 ny, plane, ntl;       // local slab: ntl time nodes
+    i64 ny, plane, ntl;       // local slab: ntl time nodes; ny = row pitch (a pad entry of a row is a mode of its own, all zeros)
     int first, last;          // slab holds global t = 0 / t = nt-1
     double beta;              // (nt-1)^2
     double kscale;            // D^2
@@ -324,7 +324,7 @@ static int tri_reg_width(i64 ntl) {
 
 static TriGeom make_geom(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc) {
     TriGeom t{};
-    t.ny = g.ny; t.plane = g.plane; t.ntl = g.ntl;
+    t.ny = g.py; t.plane = g.plane; t.ntl = g.ntl;
     t.first = g.first ? 1 : 0; t.last = g.last ? 1 : 0;
     t.beta = (double)(nt - 1) * (double)(nt - 1);
     t.kscale = kscale;

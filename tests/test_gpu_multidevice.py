@@ -213,8 +213,8 @@ def test_random_stream_stalls_change_nothing():
 
 def test_slab_threads_change_nothing():
     """One host thread per slab issues that slab's launches, copies, event records and stream waits while run() is active
-    (csrc/defer.h; the default of this mode) -- against the same runs with everything issued by the caller's thread
-    (DOTSOCP_HOST_THREADS=0).  The device sees the same operations in the same per-stream order with the same event
+    (csrc/defer.h; opt-in: DOTSOCP_HOST_THREADS=1) -- against the same runs with everything issued by the caller's thread
+    (DOTSOCP_HOST_THREADS=0, the default).  The device sees the same operations in the same per-stream order with the same event
     dependencies, so iterates, KKT histories and outputs of all three loops are bit-identical -- also under random
     stream stalls, which move the relative timing of the slab threads' work around, and with the pull launches
     replaced by event-ordered copies (many more cross-slab events per iteration)."""
