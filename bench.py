@@ -89,15 +89,15 @@ def cpu_baseline(workload, ny, nx, nt, budget_s):
     """the CPU oracle (numpy + C restatement of the reference dataflow: sparse A / A', FFT-based DCT,
     single-threaded MEX-equivalent loops, the reference's temporaries) timed on this box's host cores, with all cores
     (scipy's DCT threaded like MATLAB's fft; the rest is single-threaded in the reference too) and with ONE thread,
-    median of >= 3 single iterations each.  Bounded sample: the same spatial grid with nt = 16 time nodes (a 16-point
+    median of >= 3 single iterations each.  Bounded sample: the same spatial grid with nt = 32 time nodes (a 32-point
     t-axis DCT, all stencils at full spatial size); throughput is scaled to the full grid by the node-count ratio --
     every step of the loop is O(N) up to the log factor of the t-axis transform.  A reported baseline, not a target."""
     from oracle import driver as OD
     from oracle import examples as OE
     from oracle import model as OM
     from oracle.inpalm import InPALMState
-    nts = min(nt, 16)
-    while ny * nx * nts > 17_000_000 and nts > 4:       # set-up (sparse kron) and ~7 GB of temporaries at 16.8 M nodes
+    nts = min(nt, 32)
+    while ny * nx * nts > 34_000_000 and nts > 4:       # set-up (sparse kron) and ~14 GB of temporaries at 33.6 M nodes
         nts -= 1
     weight = None
     if workload == "dot1d":
@@ -289,7 +289,24 @@ def main():
     two_pass = bool(share) and not os.environ.get("DOTSOCP_BENCH_NOPROF")
     opts = dict(tau=1.0 if args.method == "ALG2" else 1.9, sigma=1.0, tol=0.0,
                 maxit=args.warmup + args.steps * (2 if two_pass else 1), scaling=True, ifCheckStepByStep=False, time_limit=1e9)
+    full_ms = None
     if share:
+        # the full grid first, in this same process on this same box (W warm-up, K timed iterations, no per-phase events): the
+        # ceiling T(full grid) / T(rank's share) is only meaningful as a same-run pair
+        fvar, fmodel, _, _, _ = build_problem(D, "dot2d", ny, nx, nt)
+        fopts = dict(opts, maxit=args.warmup + args.steps)
+        fctx = D.InPALMContext(fvar, fopts, fmodel, weighted=False, device=device, profiling=False, method=args.method)
+        assert fctx.run(args.warmup) == args.warmup
+        fctx.synchronize()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        assert fctx.run(args.steps) == args.steps
+        fctx.synchronize()
+        torch.cuda.synchronize()
+        full_ms = (time.perf_counter() - tf0) / args.steps * 1e3
+        fctx.finish(download=False)
+        fctx.close()
+        del fctx, fvar, fmodel
         # the middle slab of the N-way split: both neighbours exist, every exchange of a real rank takes place
         weight = None
         share_rank = share // 2
@@ -371,7 +388,7 @@ def main():
     # last chunk, which alone reads the q halo): the average interval covers half of the slab's cells
     slab_mode = world > 1 or args.nslabs > 1 or bool(share)
     cone_parts = 2 if (slab_mode and ncl >= 12 and os.environ.get("DOTSOCP_OVERLAP", "1") != "0"
-                       and os.environ.get("DOTSOCP_SPLIT_CONE", "1") != "0" and args.method in ("inPALM", "ALG2")) else 1
+                       and args.method in ("inPALM", "ALG2")) else 1
     alg_bytes /= cone_parts
     achieved = alg_bytes / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
     # HBM bytes of the dominant kernel by the PMC counters: a figure of the builder's profiling run of THIS round's build
@@ -447,6 +464,10 @@ def main():
     if share:
         out["rank_share"] = {"n": share, "slab": share // 2, "time_nodes": int(ntl),
                              "kernel_ms_sum": round(sum(v[0] * v[1] for v in times.values()) / max(args.steps, 1), 4),
+                             "full_grid_ms_per_step": full_ms,
+                             "ceiling": (full_ms / (dt / args.steps * 1e3)) if full_ms else None,
+                             "ceiling_note": "T(full grid) / T(this rank's share), both timed in THIS run (same process, same box, same "
+                                             "W and K, no per-phase events): the compute-only ceiling of the N-GPU strong-scaling curve",
                              "timed_pass": "without per-phase HIP events; kernel_ms / roofline come from a second pass of the same "
                                            "length with them" if two_pass else "with per-phase HIP events",
                              "note": "kernel_ms_sum = per-iteration sum of the phase timers (HIP events on the launch streams; "

@@ -1590,10 +1590,7 @@ static bool dct_pipe_enabled() {
     return on;
 }
 
-static bool dct_wg_enabled() {
-    static const bool on = !(getenv("DOTSOCP_DCT_WG") && atoi(getenv("DOTSOCP_DCT_WG")) == 0);
-    return on;
-}
+static bool dct_wg_enabled() { return true; }
 
 static int launch_strided(int mode, const DctPlan *p, const double *src, double *dst, const LineMap &map,
                           const SolveArgs &sa, hipStream_t st) {
@@ -1680,7 +1677,7 @@ static int launch_strided(int mode, const DctPlan *p, const double *src, double 
         }
         // long lines: one workgroup of 1024 threads with the whole LDS (twice the rows) keeps 16 waves per CU
         // like two workgroups of 512 would, and widens the contiguous segment per line to 128 bytes
-        static const bool wide = !(getenv("DOTSOCP_DCT_WIDE") && atoi(getenv("DOTSOCP_DCT_WIDE")) == 0);
+        const bool wide = true;
         const size_t lds2 = lds * 2;
         if (wide && lds2 <= DCT_LDS_MAX && lds2 > DCT_LDS_MAX / 2 && map.nLines >= ((i64)4 << lp)) {
             const int lp2 = lp + 1;
@@ -1872,13 +1869,8 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             set_error("dense DCT path needs distinct src/dst");
             return DOTSOCP_EINVAL;
         }
-        static const int dense_mode = [] {      // DOTSOCP_DENSE = mfma (default) | kernel
-            const char *e = getenv("DOTSOCP_DENSE");
-            return (e && strcmp(e, "kernel") == 0) ? 2 : 0;
-        }();
-        static const bool split = !(getenv("DOTSOCP_MFMA_SPLIT") && atoi(getenv("DOTSOCP_MFMA_SPLIT")) == 0);
-        if (dense_mode == 0 && split && p->Ef && map.nLines >= 64) {
-            static const int mfma_xcd = getenv("DOTSOCP_MFMA_XCD") ? atoi(getenv("DOTSOCP_MFMA_XCD")) : 1;
+        if (p->Ef && map.nLines >= 64) {
+            const int mfma_xcd = 1;
             SplitArgs sp{inverse ? p->Ei : p->Ef, inverse ? p->Oi : p->Of, p->ne, p->no, p->h, p->njE, mfma_xcd};
             const unsigned lt = (unsigned)((map.nLines + MF_LT - 1) / MF_LT);
             if (inverse) {
@@ -1893,17 +1885,11 @@ int launch_dct_axis(const DctPlan *p, const double *src, double *dst, i64 n0, i6
             DS_HIP(hipGetLastError());
             return 0;
         }
-        if (dense_mode == 0 && n >= 48 && map.nLines >= 64) {
+        if (n >= 48 && map.nLines >= 64) {
             const double *Mm = inverse ? p->Cinv : p->Cfwd;
             dim3 grid((unsigned)((n + MF_KT - 1) / MF_KT), (unsigned)((map.nLines + MF_LT - 1) / MF_LT));
-            static const int kc = getenv("DOTSOCP_MFMA_KC") ? atoi(getenv("DOTSOCP_MFMA_KC")) : 8;
-            if (kc == 8) {
-                if (axis == 0) DS_KLAUNCH((k_dct_mfma<true, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-                else DS_KLAUNCH((k_dct_mfma<false, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-            } else {
-                if (axis == 0) DS_KLAUNCH((k_dct_mfma<true, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-                else DS_KLAUNCH((k_dct_mfma<false, 16>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
-            }
+            if (axis == 0) DS_KLAUNCH((k_dct_mfma<true, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
+            else DS_KLAUNCH((k_dct_mfma<false, 8>), grid, dim3(256), 0, st, src, dst, map, (int)n, Mm);
             DS_HIP(hipGetLastError());
             return 0;
         }

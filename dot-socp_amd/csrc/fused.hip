@@ -172,15 +172,10 @@ bool stream_nt_enabled() {
 }
 
 bool tile_xcd_remap(const Grid &g) {
-    static const int forced = getenv("DOTSOCP_XCD") ? atoi(getenv("DOTSOCP_XCD")) : -1;
-    if (forced >= 0) return forced != 0;
     return (g.py % 16) != 0;
 }
 
-bool cone_split_enabled() {
-    static const bool on = !(getenv("DOTSOCP_SPLIT_CONE") && atoi(getenv("DOTSOCP_SPLIT_CONE")) == 0);
-    return on;
-}
+bool cone_split_enabled() { return true; }
 
 int fused_geometry(const Grid &g, FusedGeom &fg) {
     fg.XB = 4;
@@ -188,7 +183,7 @@ int fused_geometry(const Grid &g, FusedGeom &fg) {
     fg.nxblk = (g.nx + fg.XB - 1) / fg.XB;
     const i64 tiles = fg.nyblk * fg.nxblk;
     // enough workgroups to fill 256 CUs several times over; each extra chunk costs one recomputed cell
-    static const i64 target = getenv("DOTSOCP_CONE_BLOCKS") ? atoll(getenv("DOTSOCP_CONE_BLOCKS")) : 2048;
+    const i64 target = 2048;
     i64 chunks = (target + tiles - 1) / tiles;
     if (chunks < 1) chunks = 1;
     // a slab of a time-slab decomposition: at least two chunks (see cone_split_enabled)

@@ -88,7 +88,7 @@ int fused_geometry(const Grid &g, FusedGeom &fg);
 int launch_cone_fused(int mode, const Grid &g, const LoopCoef &c, const FusedGeom &fg, FusedArgs a,
                       hipStream_t st, i64 z0 = 0, i64 zcount = -1);
 // time-slab mode: split every slab's cone pass into >= 2 chunks so that the chunks in front of the last one --
-// which alone reads the q halo -- can start before the halo has arrived (DOTSOCP_SPLIT_CONE=0 disables)
+// which alone reads the q halo -- can start before the halo has arrived
 bool cone_split_enabled();
 
 // ---------------- acc.hip (acc-ADMM loop) ----------------

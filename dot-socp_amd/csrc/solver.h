@@ -88,6 +88,8 @@ struct Slab {
     // fused path (fused.hip): q^{k-1}, adjoint sums, ping-pong beta, tile-boundary side buffers
     double *q_old = nullptr, *q2 = nullptr, *beta2 = nullptr, *sx = nullptr, *sy = nullptr;
     double *q3 = nullptr, *p2 = nullptr, *sxp = nullptr, *syp = nullptr;    // PALM, one pass over beta per iteration (solver_palm.hip)
+    // ... on time slabs: the second gather's share of the neighbour's first edge layer (sent to the right / received from the left)
+    double *send_pbx = nullptr, *send_pby = nullptr, *ptail_bx = nullptr, *ptail_by = nullptr;
     double *alpha2 = nullptr;   // ping-pong partner of alpha (q-step that also forms the next rhs)
     // partitioned tridiagonal t-solve (tri.hip): messages to / from the owners of the modes, zero-mode work line
     double *tri_send = nullptr, *tri_recv = nullptr, *tri_bsend = nullptr, *tri_brecv = nullptr, *tri_zero = nullptr;
@@ -274,7 +276,7 @@ struct Solver {
     int tri_alloc();
     int tri_exchange(bool back);
     int poisson_t_tridiag(const PhiHooks *hooks);
-    bool qrhs = true;        // DOTSOCP_QRHS=0: separate q-step and rhs kernels
+    const bool qrhs = true;  // the fused dataflow's q-step also forms the next right-hand side (k_qstep_rhs)
     bool rhs_valid = false;  // w0 holds A'(w.*q - alpha) + c of the current iterate (left there by the q-step)
     // the q halo / u0 tail of the newest iterate have not been exchanged yet: step() issues the exchange behind the
     // fork so that the cone chunks that do not read the halo overlap it; every other reader calls ensure_halo()
@@ -323,7 +325,7 @@ struct Solver {
                         double *bx, double *by);
     int jump_from(Solver &coarse);
     // PALM (solver_palm.hip)
-    bool palm_fast = true;     // one slab: one pass over beta per iteration (DOTSOCP_PALM_FAST=0: the two-pass dataflow)
+    bool palm_fast = true;     // one pass over beta per iteration (DOTSOCP_PALM_FAST=0: the two-pass dataflow)
     bool palm_p_valid = false; // p2 / sxp / syp hold the second gather of the last cone pass
     int palm_begin();
     int palm_step(bool *brk);

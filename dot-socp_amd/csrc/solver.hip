@@ -213,6 +213,7 @@ void Solver::free_slabs() {
         dfree(s.kw.partials); dfree(s.kw.sums);
         dfree(s.q_old); dfree(s.q2); dfree(s.beta2); dfree(s.sx); dfree(s.sy); dfree(s.alpha2);
         dfree(s.q3); dfree(s.p2); dfree(s.sxp); dfree(s.syp);
+        dfree(s.send_pbx); dfree(s.send_pby); dfree(s.ptail_bx); dfree(s.ptail_by);
         dfree(s.carry);
         dfree(s.tri_send); dfree(s.tri_recv); dfree(s.tri_bsend); dfree(s.tri_brecv); dfree(s.tri_zero);
         dfree(s.phi_p); dfree(s.alpha_p); dfree(s.z_p);
@@ -322,7 +323,6 @@ int Solver::init(const dotsocp_problem *p, int dev, int nslabs, bool multi_dev) 
     DS_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
     overlap = nslabs > 1;                         // pays when there is communication to hide
     if (const char *e = getenv("DOTSOCP_OVERLAP")) overlap = (atoi(e) != 0);
-    if (const char *e = getenv("DOTSOCP_QRHS")) qrhs = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_KKT_FOLD")) kkt_fold = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_NORM_CACHE")) norm_cache = (atoi(e) != 0);
     if (const char *e = getenv("DOTSOCP_TSOLVE")) tri_tsolve = (strcmp(e, "dct") != 0);
@@ -347,12 +347,8 @@ int Solver::ensure_alloc() {
 // no multiple of 16 doubles -- the 2^k+1 grids of the reference's multilevel driver -- padded to the next multiple of
 // 128 bytes; time-slab contexts keep the reference layout (their messages and the partitioned t-solve index the
 // (y, x) columns of a layer linearly).  DOTSOCP_PITCH=0: never.
-// pad between the ten columns of z and beta (common.h: Grid::Nc); DOTSOCP_COLPAD=0: none
-i64 Solver::column_pad() const {
-    const char *e = getenv("DOTSOCP_COLPAD");
-    const i64 v = e ? atoll(e) : 48;
-    return (v > 0 && ny * nx >= 4096) ? v : 0;
-}
+// pad between the ten columns of z and beta (common.h: Grid::Nc)
+i64 Solver::column_pad() const { return (ny * nx >= 4096) ? 48 : 0; }
 
 i64 Solver::row_pitch() const {
     static const bool on = !(getenv("DOTSOCP_PITCH") && atoi(getenv("DOTSOCP_PITCH")) == 0);
@@ -860,7 +856,9 @@ int Solver::tri_exchange(bool back) {
         if (gather) {
             bool one = true;
             for (auto &s : slabs) one = one && cst(s) == cst(slabs[0]);
-            if (!one) FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, cst(s)));
+            if (!one) {
+                FOR_SLABS(s) DS_HIP(ds_event_record(s.ev_tri, cst(s)));
+            }
             FOR_SLABS(sd) {                 // receiver: owner j (forward), slab p (back)
                 GatherMsgs m{};
                 m.n = 0;

@@ -14,7 +14,7 @@
 //   q^{k+1}, alpha^{k+1}                                      -> s.q                       (:215-217,221,225)
 //   beta^{k+1}: deferred to pass 1 of the next iteration (or to the KKT block)              (:222-226)
 //
-// One slab (palm_fast): ONE pass over beta per iteration.  F*B*BF is diagonal and F*B*d = 0, so the gather of pass 1,
+// palm_fast: ONE pass over beta per iteration.  F*B*BF is diagonal and F*B*d = 0, so the gather of pass 1,
 //   F*B*(z^k + beta^k) = F*B*((1 + tau) z^k + beta^{k-1}) - tau F*B*(BF q^k + d),
 // needs no pass over beta: the cone pass of iteration k-1 emits p2 = F*B*((1 + tau) z^k + beta^{k-1}) as a second gather
 // beside the q2 of its own q-step (k_cone_fused modes 5 / 6), and the first q-step of iteration k subtracts the
@@ -24,6 +24,9 @@
 //           z^{k+1} = Pi(BF q~^k + d - beta^k), q2 = F*B*(z^{k+1} + beta^k), p2 = F*B*((1 + tau) z^{k+1} + beta^k)
 // Right after a KKT or rescale block (multiplier step executed, z regenerated on demand) the iteration runs as above with
 // mode 6 (= mode 0 + p2) as its pass 2.
+// Time slabs (round 4): the same dataflow.  The second gather's share of the right neighbour's first edge layer travels
+// with the first gather's (one more pair of tail layers in the group behind the cone pass), q~^k lives in q3 when the pass
+// is mode 5 -- its halo and the u0 tail are taken from there --, and the element-wise term needs no neighbour.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -56,13 +59,21 @@ int Solver::palm_begin() {
     z_valid = true;
     if (const char *e = getenv("DOTSOCP_PALM_FAST")) palm_fast = (atoi(e) != 0);
     palm_p_valid = false;
-    if (palm_fast && !multi()) {
+    if (palm_fast) {
         FOR_SLABS(s) {
             if (s.q3) continue;
             DS_CHECK(dzalloc(&s.q3, s.g.NqAlloc, s.st));
             DS_CHECK(dzalloc(&s.p2, s.g.NqAlloc, s.st));
             DS_CHECK(dzalloc(&s.sxp, s.fg.sx_len, s.st));
             DS_CHECK(dzalloc(&s.syp, s.fg.sy_len, s.st));
+            if (multi() && !s.g.first) {
+                DS_CHECK(dzalloc(&s.ptail_bx, s.g.bxLayer, s.st));
+                DS_CHECK(dzalloc(&s.ptail_by, s.g.byLayer, s.st));
+            }
+            if (multi() && !s.g.last) {
+                DS_CHECK(dzalloc(&s.send_pbx, s.g.bxLayer, s.st));
+                DS_CHECK(dzalloc(&s.send_pby, s.g.byLayer, s.st));
+            }
         }
     }
     return 0;
@@ -74,13 +85,13 @@ int Solver::palm_step(bool *brk) {
     DS_CHECK(rescale_block());            // :142-194 (scales phi in place of tmp_q for this method)
     // ---- first q-step :196-200 ----
     prof_begin(PH_QSTEP0);
-    const bool fast = palm_fast && !multi();
+    const bool fast = palm_fast;
     // the gather comes from the last cone pass's second output; the multiplier step stays pending until this iteration's pass
     const bool three = fast && deferred && palm_p_valid;
     if (three) {
         FOR_SLABS(s)
-            DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.p2, s.sxp, s.syp, s.c, s.q3, s.alpha, s.w0, s.st, nullptr,
-                                             nullptr, s.q));
+            DS_CHECK(launch_qstep_palm_first(s.g, lc, s.fg, s.phi, s.p2, s.sxp, s.syp, s.c, s.q3, s.alpha, s.w0, s.st, s.ptail_bx,
+                                             s.ptail_by, s.q));      // (time slabs: the tails came with the last cone pass's)
     } else if (deferred) {
         FOR_SLABS(s) {
             FusedArgs a{};
@@ -114,9 +125,10 @@ int Solver::palm_step(bool *brk) {
         // q~ halo -> left (projection of the last cell layer), u0 = q~0 - alpha0 of the last cell -> right (first rhs layer)
         prof_begin(PH_COMM);
         FOR_SLABS(s)
-            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, s.q_old, s.alpha, nullptr, s.send_plane, s.st));
+            if (!s.g.last) DS_CHECK(launch_u0_tail(s.g, three ? s.q3 : s.q_old, s.alpha, nullptr, s.send_plane, s.st));
         DS_CHECK(group_begin());
-        DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
+        if (three) DS_CHECK(shift_edge_halo([](Slab &s) { return s.q3; }));
+        else DS_CHECK(shift_edge_halo([](Slab &s) { return s.q_old; }));
         DS_CHECK(shift(+1, [](Slab &s) { return s.send_plane; }, [](Slab &s) { return s.u0_prev; }, slabs[0].g.plane));
         DS_CHECK(group_end());
         FOR_SLABS(s)
@@ -153,7 +165,22 @@ int Solver::palm_step(bool *brk) {
     prof_end(three ? PH_FUSED_B : PH_FUSED_A);
     z_valid = false;
     z_prev_ok = false;
-    DS_CHECK(phase_z_tails());            // time slabs: phi^{k+1} head -> left, adjoint tails -> right
+    if (multi()) {
+        // time slabs: phi^{k+1} head -> left, adjoint tails of both gathers -> right, one group
+        DS_CHECK(make_tails());
+        if (fast) {
+            FOR_SLABS(s)
+                if (!s.g.last) DS_CHECK(launch_tail_finalize(s.g, lc, s.fg, s.p2, s.sxp, s.syp, s.send_pbx, s.send_pby, s.st));
+        }
+        DS_CHECK(group_begin());
+        DS_CHECK(send_phi_head());
+        DS_CHECK(send_tails());
+        if (fast) {
+            DS_CHECK(shift(+1, [](Slab &s) { return s.send_pbx; }, [](Slab &s) { return s.ptail_bx; }, slabs[0].g.bxLayer));
+            DS_CHECK(shift(+1, [](Slab &s) { return s.send_pby; }, [](Slab &s) { return s.ptail_by; }, slabs[0].g.byLayer));
+        }
+        DS_CHECK(group_end());
+    }
     // ---- second q-step + alpha :213-218,221,225 ----
     // Whether the iteration ends with a KKT check (:231-232) is known here (the time limit is the one trigger that is
     // not: such a check takes the unfolded block).  If it does, the q-step runs in the flavour that accumulates its share

@@ -814,7 +814,7 @@ i64 qstep_rhs_chunks(const Grid &g, const FusedGeom &fg, i64 *TCout) {
     // short chunks of time layers (measured at 1024x1024x128: 3.45 ms with 8-layer chunks, 4.2 ms with one chunk per
     // tile -- the march is latency-bound per workgroup); each extra chunk recomputes one cell
     const i64 tiles = fg.nyblk * fg.nxblk;
-    static const i64 target = getenv("DOTSOCP_QRHS_BLOCKS") ? atoll(getenv("DOTSOCP_QRHS_BLOCKS")) : 32768;
+    const i64 target = 32768;
     i64 chunks = (target + tiles - 1) / tiles;
     i64 TC = (g.ntl + chunks - 1) / chunks;
     if (TC < 8) TC = 8;
@@ -842,8 +842,7 @@ static int launch_qstep_rhs_var(int var, const Grid &g, const LoopCoef &c, const
     a.TC = TC;
     a.z0 = z0;
     a.zstride = zstride;
-    static const int xcd = getenv("DOTSOCP_QXCD") ? atoi(getenv("DOTSOCP_QXCD")) : 1;
-    a.xcd = xcd;
+    a.xcd = 1;
     dim3 grid((unsigned)fg.nyblk, (unsigned)fg.nxblk, (unsigned)zcount);
     dim3 blk(TILE_Y, TILE_X);
     // the plain inPALM instance may run on tiles twice as wide (the recomputed x - 1 edge and the phi halo columns cost

@@ -317,8 +317,6 @@ __global__ void __launch_bounds__(256) k_tri_final_reg(TriGeom g, const double *
 }
 
 static int tri_reg_width(i64 ntl) {
-    static const bool on = !(getenv("DOTSOCP_TRI_REG") && atoi(getenv("DOTSOCP_TRI_REG")) == 0);
-    if (!on) return 0;
     return ntl <= 16 ? 16 : (ntl <= 32 ? 32 : (ntl <= 64 ? 64 : 0));
 }
 

@@ -110,7 +110,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     struct ncclComm *c = (struct ncclComm *)calloc(1, sizeof *c);
     c->rank = rank;
     c->nranks = nranks;
-    strncpy(c->tag, id.internal, sizeof c->tag - 1);
+    /* the id may come from the real librccl (a test process that loaded it earlier hands out ITS unique ids): arbitrary
+     * bytes, '/' included -- the shared-memory names take a hex digest of the first 16 of them */
+    for (int i = 0; i < 16; ++i) snprintf(c->tag + 2 * i, 3, "%02x", (unsigned)(unsigned char)id.internal[i]);
     *comm = c;
     return ncclSuccess;
 }

@@ -73,3 +73,35 @@ def test_gpu_translation_of_a_gaussian_in_2d(method):
     cost = float(np.mean(np.where(ok, (out["Ex"] ** 2 + out["Ey"] ** 2) / np.where(ok, out["rho"], 1.0), 0.0)))
     w2 = (cy1 - cy0) ** 2 + (cx1 - cx0) ** 2
     assert abs(cost - w2) <= 0.02 * w2, (cost, w2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx,nt,levels", [(257, 257, 65, 4), (193, 193, 49, 3)])
+def test_gpu_translation_of_a_gaussian_in_2d_at_other_sizes(ny, nx, nt, levels):
+    """The same closed-form anchor at a second and a third size (round-3 verdict, item 8): a finer square grid, where the
+    discretisation error of density and cost must shrink, and a grid whose lengths are neither powers of two nor 2^k + 1
+    (193 = 3 * 64 + 1, 49 = 3 * 16 + 1: the dense DCT product on the matrix cores on every axis; square, because the
+    reference's restriction downSample_phi.m:5-34 indexes rows and columns with the row range)."""
+    import dotsocp_amd as D
+    s = 0.06
+    Y, X = np.meshgrid(np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+
+    def bump(cy, cx):
+        g = np.exp(-0.5 * (((Y - cy) / s) ** 2 + ((X - cx) / s) ** 2))
+        return g / g.mean()
+
+    (cy0, cx0), (cy1, cx1) = (0.3, 0.35), (0.7, 0.6)
+    out, timeML, histML, hist = D.solver_dotsocp2d(bump(cy0, cx0), bump(cy1, cx1), nt, levels, dict(tol=1e-5, maxit=20000),
+                                                   "inPALM")
+    assert D.check_massConservation(out["rho"], 1e-2)
+    worst = 0.0
+    for k, t in enumerate(np.linspace(0, 1, nt)):
+        g = bump((1 - t) * cy0 + t * cy1, (1 - t) * cx0 + t * cx1)
+        worst = max(worst, float(np.mean(np.abs(out["rho"][:, :, k] - g))))
+    ok = out["rho"] > 1e-8
+    cost = float(np.mean(np.where(ok, (out["Ex"] ** 2 + out["Ey"] ** 2) / np.where(ok, out["rho"], 1.0), 0.0)))
+    w2 = (cy1 - cy0) ** 2 + (cx1 - cx0) ** 2
+    print(f"analytic 2-D anchor {ny}x{nx}x{nt}: worst L1 {worst:.4f}, cost {cost:.5f} vs {w2:.5f}")
+    # 129 x 129 x 33 is held to 5 % / 2 %; the finer grid must do better (observed values in DESIGN.md section 5)
+    assert worst <= (0.03 if ny == 257 else 0.05), worst
+    assert abs(cost - w2) <= (0.012 if ny == 257 else 0.02) * w2, (cost, w2)

@@ -16,7 +16,7 @@ def _relerr(a, b):
     return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
 
 
-def _compare(rho0, rho1, nt, opts, K, tol=1e-9):
+def _compare(rho0, rho1, nt, opts, K, tol=1e-9, nslabs=1):
     opts = dict(opts, maxit=K)
     ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, "PALM")
     st = PALMState(ovar, oo, omodel)
@@ -24,7 +24,7 @@ def _compare(rho0, rho1, nt, opts, K, tol=1e-9):
     o_hist, o_sigma = st.finish()
     gvar, gmodel = D.initialize(rho0, rho1, nt)
     D.InitialScaling(gvar, gmodel, oo["scaling"], None, dim=2)
-    g_hist, g_sigma = D.solver_socp_PALM(gvar, oo, gmodel)
+    g_hist, g_sigma = D.solver_socp_PALM(gvar, oo, gmodel, nslabs=nslabs)
     assert g_hist["len"] == o_hist["len"]
     np.testing.assert_array_equal(g_hist["iter"], o_hist["iter"])
     assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
@@ -43,6 +43,32 @@ def _compare(rho0, rho1, nt, opts, K, tol=1e-9):
 def test_trajectory(n, nt, K):
     rho0, rho1 = get_example_2d("example1", n, n)
     _compare(rho0, rho1, nt, dict(tol=0.0), K)
+
+
+@pytest.mark.parametrize("n,nt,K,nslabs", [(32, 16, 60, 2), (33, 49, 40, 3), (40, 36, 30, 4)])
+def test_trajectory_on_time_slabs(n, nt, K, nslabs):
+    """The one-pass dataflow on time slabs (round 4: the second gather's tails travel with the first's, q~ halo and u0 tail
+    from q3) against the oracle, over KKT checks, sigma updates and rescale blocks; slabs with and without chunked passes."""
+    rho0, rho1 = get_example_2d("example1", n, n)
+    _compare(rho0, rho1, nt, dict(tol=0.0), K, nslabs=nslabs)
+
+
+@pytest.mark.parametrize("n,nt,nslabs", [(33, 49, 3), (32, 16, 2)])
+def test_one_pass_dataflow_equals_two_pass_on_time_slabs(n, nt, nslabs, monkeypatch):
+    rho0, rho1 = get_example_2d("example1", n, n)
+    res = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("DOTSOCP_PALM_FAST", fast)
+        var, model = D.initialize(rho0, rho1, nt)
+        oo = OD.default_opts(dict(tol=0.0, maxit=40), "PALM", False)
+        D.InitialScaling(var, model, oo["scaling"], None, dim=2)
+        hist, sigma = D.solver_socp_PALM(var, oo, model, nslabs=nslabs)
+        res.append((var, hist, sigma))
+    (a, ha, sa), (b, hb, sb) = res
+    assert abs(sa - sb) <= 1e-13 * abs(sb)
+    np.testing.assert_array_equal(ha["iter"], hb["iter"])
+    errs = {f: _relerr(getattr(a, f), getattr(b, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-11, errs
 
 
 def test_trajectory_rectangular_checkstep():

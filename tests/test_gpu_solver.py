@@ -225,6 +225,37 @@ def test_time_slabs_match_single_slab(case, nslabs, tsolve, request, monkeypatch
     assert max(errs.values()) <= (1e-8 if weight is not None else 1e-10), errs
 
 
+@pytest.mark.parametrize("case", ["dot2d_33x33x49", "dot2d_32x32x16", "dot2d_40x24x36"])
+def test_messages_on_second_streams_change_nothing(case, request, monkeypatch):
+    """Time slabs: by default every message between slabs (halos, tails, the interface exchanges of the partitioned t-solve)
+    and the two small kernels between those exchanges travel on the slabs' second streams while the main streams run the
+    kernels that do not need them (Solver::step, comm_z); DOTSOCP_OVERLAP=0 issues everything on the main streams, one
+    after the other.  Same kernels on the same data in both orders: the iterates must be bit-identical -- in-process slabs
+    with their own stream pairs (ngpu, the multi-device placement) and sharing the device's pair (nslabs)."""
+    if "unfused" in request.node.name:
+        pytest.skip("time slabs exist on the fused dataflow only")
+    a, b, nt = [int(v) for v in case.split("_")[1].split("x")]
+    rho0, rho1 = get_example_2d("example1", a, b)
+    opts = dict(tol=0.0, maxit=25)
+    for kw in (dict(nslabs=3), dict(ngpu=3)):
+        runs = []
+        for ov in ("1", "0"):
+            monkeypatch.setenv("DOTSOCP_OVERLAP", ov)
+            var, model, o = _gpu_level(rho0, rho1, nt, opts, "inPALM", None)
+            ctx = D.InPALMContext(var, o, model, weighted=False, **kw)
+            try:
+                ctx.run(-1)
+                hist, sigma = ctx.finish()
+            finally:
+                ctx.close()
+            runs.append((var, hist, sigma))
+        (v1, h1, s1), (v0, h0, s0) = runs
+        np.testing.assert_array_equal(h1["kkt"], h0["kkt"])
+        assert s1 == s0
+        for f in FIELDS:
+            np.testing.assert_array_equal(getattr(v1, f), getattr(v0, f))
+
+
 def test_time_slabs_free_running_against_oracle(request):
     if "unfused" in request.node.name:
         pytest.skip("time slabs exist on the fused dataflow only")
