@@ -33,11 +33,6 @@ struct TriGeom {
 
 __device__ __forceinline__ double tri_aprime(const TriGeom &g, i64 m) { return (g.cy[m % g.ny] + g.cx[m / g.ny]) / g.beta; }
 
-// delta_t of a block with n rows: a' + 2, minus 1 on the global first / last row
-__device__ __forceinline__ double tri_delta(double ap, i64 t, i64 n, bool first, bool last) {
-    return ap + 2.0 - ((first && t == 0) ? 1.0 : 0.0) - ((last && t == n - 1) ? 1.0 : 0.0);
-}
-
 __device__ __forceinline__ int tri_owner(const PencilCuts &pc, i64 m, i64 plane) {
     int j = (int)((m * pc.world) / plane);
     while (j > 0 && m < pc.cut[j]) --j;
@@ -48,36 +43,110 @@ __device__ __forceinline__ int tri_owner(const PencilCuts &pc, i64 m, i64 plane)
 // message to owner j starts at 2 cut[j] + TRI_EXTRA j and holds [first values | last values | TRI_EXTRA extras]
 __device__ __forceinline__ i64 tri_msg_off(const PencilCuts &pc, int j) { return 2 * pc.cut[j] + (i64)TRI_EXTRA * j; }
 
+// ---- division-free eliminations (round 4) ----
+// The pivots of a block depend on the mode and the row only, and have a closed form.  With x = 1 + a'/2 = cosh(theta),
+// r = e^theta = x + sqrt(x^2 - 1), rho = 1 / r, the elimination from a block's first row gives
+//     piv_t = r N_{t+1} / N_t ,   N_t = 1 - rho^(2t+2)  (row 0 couples to a neighbour slab: delta_0 = a' + 2)
+//                                 N_t = 1 + rho^(2t+1)  (row 0 is the global first / last row: delta_0 = a' + 1)
+// (both satisfy N_{t+1} = (1 - rho^2) + rho^2 N_t -- a recurrence of positive terms, no cancellation), and a global
+// boundary row at the END of the sweep has piv = r N_n / N_{n-1} - 1.  In the scaled variable D_t = d_t N_t the sweep
+// d_t = g_t + d_{t-1} / piv_{t-1} becomes  D_t = g_t N_t + rho D_{t-1}:  no division per row (the kernels of round 2
+// spent 2 n dependent IEEE divisions per mode here and were bound by them: 43 + 57 us on a slab of 16 layers that
+// streams in 27 + 54, 530 + 630 us on 64 layers).  The last unknown is rho D_{n-1} / N_n (boundary end:
+// D_{n-1} / (r N_n - N_{n-1})).  The sweep from the other end is the same recurrence on the reversed column; as a
+// weighted sum, sum_t rho^t N'_{n-1-t} g_t, it runs in the same ascending pass over the column.
+struct TriCoef {
+    double rho, rho2, r, r2, n0d;      // n0d = 1 - rho^2, formed without cancellation
+};
+__device__ __forceinline__ TriCoef tri_coef(double ap) {
+    TriCoef c;
+    const double s = sqrt(ap * (1.0 + 0.25 * ap));     // sqrt(x^2 - 1)
+    const double rm1 = 0.5 * ap + s;                    // r - 1
+    c.r = 1.0 + rm1;
+    c.rho = 1.0 / c.r;
+    c.rho2 = c.rho * c.rho;
+    c.r2 = c.r * c.r;
+    c.n0d = (rm1 * c.rho) * (1.0 + c.rho);              // (1 - rho) (1 + rho)
+    return c;
+}
+__device__ __forceinline__ double tri_n0(const TriCoef &c, bool bnd) { return bnd ? 1.0 + c.rho : c.n0d; }
+// x / n for n in (0, 2]: reciprocal seed, two Newton steps, one residual correction (the result of the IEEE sequence to
+// the last bit or one off it, at about half its instructions)
+__device__ __forceinline__ double tri_div(double x, double n) {
+    double r = __builtin_amdgcn_rcp(n);
+    double e = __builtin_fma(-n, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-n, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    return __builtin_fma(__builtin_fma(-n, q, x), r, q);
+}
+// The sequence N_j, j = 0 .. n, of a sweep that starts on a boundary row (bnd) or not: its last two members, and what a
+// DOWNWARD walk through the powers rho^(2j+e) needs to stay clear of underflow: above `jsave` the power is below 1e-20
+// (N_j = 1 to the last bit), at jsave it is `psave`, below it grows by r^2 per step.
+struct TriSeq {
+    int jsave;
+    double psave, N1, Nn;              // N_{n-1}, N_n
+};
+__device__ __forceinline__ TriSeq tri_seq(const TriCoef &c, bool bnd, int n) {
+    TriSeq w{-1, 0.0, 0.0, 0.0};
+    double P = bnd ? c.rho : c.rho2, N = tri_n0(c, bnd);
+    for (int j = 0; j < n; ++j) {
+        if (P >= 1e-20) { w.jsave = j; w.psave = P; }
+        P *= c.rho2;
+        if (j + 1 < n) N = c.n0d + c.rho2 * N;
+    }
+    w.N1 = N;
+    w.Nn = c.n0d + c.rho2 * N;
+    return w;
+}
+// the last unknown of a sweep over n rows from its D_{n-1}; bnd: the sweep ENDS on a global boundary row
+__device__ __forceinline__ double tri_last(const TriCoef &c, double D, double N1, double Nn, bool bnd) {
+    return bnd ? tri_div(D, c.r * Nn - N1) : tri_div(c.rho * D, Nn);
+}
+
+// One ascending pass over the column of a mode: both eliminations at once, nothing kept (any slab length)
 __global__ void __launch_bounds__(256) k_tri_local(TriGeom g, const double *__restrict__ r, double *__restrict__ send) {
     const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
     if (m >= g.plane) return;
-    const double ap = tri_aprime(g, m);
     const double sc = 1.0 / (g.kscale * g.beta);
-    const i64 n = g.ntl;
-    auto G = [&](i64 t) { return r[m + g.plane * t] * sc; };
-    // elimination from the front: last entry of A^{-1} g
-    double piv = tri_delta(ap, 0, n, g.first, g.last), d = G(0);
-    for (i64 t = 1; t < n; ++t) {
-        const double inv = 1.0 / piv;
-        d = G(t) + d * inv;
-        piv = tri_delta(ap, t, n, g.first, g.last) - inv;
-    }
-    const double Gl = d / piv;
-    // elimination from the back: first entry
-    piv = tri_delta(ap, n - 1, n, g.first, g.last);
-    d = G(n - 1);
-    for (i64 t = n - 2; t >= 0; --t) {
-        const double inv = 1.0 / piv;
-        d = G(t) + d * inv;
-        piv = tri_delta(ap, t, n, g.first, g.last) - inv;
-    }
-    const double Gf = d / piv;
+    const int n = (int)g.ntl;
     const int j = tri_owner(g.pc, m, g.plane);
     const i64 off = tri_msg_off(g.pc, j), w = g.pc.cut[j + 1] - g.pc.cut[j];
-    send[off + (m - g.pc.cut[j])] = Gf;
-    send[off + w + (m - g.pc.cut[j])] = Gl;
-    if (m == 0)                                   // the singular mode travels whole
-        for (i64 t = 0; t < n; ++t) send[off + 2 * w + t] = G(t);
+    if (m == 0) {                                 // the singular mode travels whole
+        for (int t = 0; t < n; ++t) send[off + 2 * w + t] = r[g.plane * t] * sc;
+        send[off] = 0.0;
+        send[off + w] = 0.0;
+        return;
+    }
+    const TriCoef c = tri_coef(tri_aprime(g, m));
+    const bool first = g.first != 0, last = g.last != 0;
+    // from the front: D_t = g_t N_t + rho D_{t-1}; from the back, as a weighted sum: F = sum_t rho^t N'_{n-1-t} g_t
+    const TriSeq sb = tri_seq(c, last, n);        // the reversed column starts on the slab's LAST row
+    const double sgn = last ? 1.0 : -1.0;
+    double N = tri_n0(c, first), N1 = N, D = 0.0, F = 0.0, pw = 1.0, Pb = 0.0;
+    constexpr int U = 4;
+    for (int t0 = 0; t0 < n; t0 += U) {
+        double gv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) gv[u] = (t0 + u < n) ? r[m + g.plane * (t0 + u)] * sc : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            if (t < n) {
+                D = gv[u] * N + c.rho * D;
+                N1 = N;
+                N = c.n0d + c.rho2 * N;                    // N_{t+1}
+                const int jb = n - 1 - t;
+                if (jb == sb.jsave) Pb = sb.psave;
+                else if (jb < sb.jsave) Pb *= c.r2;
+                F += (pw * (1.0 + sgn * Pb)) * gv[u];
+                pw *= c.rho;
+            }
+        }
+    }
+    send[off + (m - g.pc.cut[j])] = tri_last(c, F, sb.N1, sb.Nn, first);      // first entry of A^-1 g
+    send[off + w + (m - g.pc.cut[j])] = tri_last(c, D, N1, N, last);          // last entry
 }
 
 struct TriReduced {
@@ -130,29 +199,35 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
         for (int p = 0; p < q.P; ++p) { msg_out(p)[i] = 0.0; msg_out(p)[q.nl + i] = 0.0; }
         return;
     }
-    const double ap = tri_aprime(g, m);
+    const TriCoef c = tri_coef(tri_aprime(g, m));
     double A[PMAX], B[PMAX], al[PMAX], ga[PMAX];
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
         if (p >= q.P) break;
-        const i64 n = q.slab_n[p];
+        const int n = (int)q.slab_n[p];
         const bool first = (p == 0), last = (p == q.P - 1);
-        // first / last entries of A_p^{-1} e_first (vf, vl) and A_p^{-1} e_last (wf, wl)
-        double piv = tri_delta(ap, 0, n, first, last), prod = 1.0;
-        for (i64 t = 1; t < n; ++t) {
-            const double inv = 1.0 / piv;
-            prod *= inv;
-            piv = tri_delta(ap, t, n, first, last) - inv;
+        // first / last entries of A_p^{-1} e_first (vf, vl) and A_p^{-1} e_last (wf, wl) in closed form:
+        // prod_{s < n-1} 1 / piv_s = rho^(n-1) N_0 / N_{n-1}, 1 / piv_{n-1} = rho N_{n-1} / N_n (boundary end: N_{n-1} / (r N_n - N_{n-1}))
+        const TriSeq sf = tri_seq(c, first, n), sb = tri_seq(c, last, n);
+        double rn1 = 1.0;                                  // rho^(n-1)
+        for (int t = 1; t < n; ++t) rn1 *= c.rho;
+        double vl, wl, vf, wf;
+        if (last) {
+            const double den = c.r * sf.Nn - sf.N1;
+            vl = tri_div(rn1 * tri_n0(c, first), den);
+            wl = tri_div(sf.N1, den);
+        } else {
+            vl = tri_div((rn1 * c.rho) * tri_n0(c, first), sf.Nn);
+            wl = tri_div(c.rho * sf.N1, sf.Nn);
         }
-        double vl = prod / piv, wl = 1.0 / piv;
-        piv = tri_delta(ap, n - 1, n, first, last);
-        prod = 1.0;
-        for (i64 t = n - 2; t >= 0; --t) {
-            const double inv = 1.0 / piv;
-            prod *= inv;
-            piv = tri_delta(ap, t, n, first, last) - inv;
+        if (first) {
+            const double den = c.r * sb.Nn - sb.N1;
+            wf = tri_div(rn1 * tri_n0(c, last), den);
+            vf = tri_div(sb.N1, den);
+        } else {
+            wf = tri_div((rn1 * c.rho) * tri_n0(c, last), sb.Nn);
+            vf = tri_div(c.rho * sb.N1, sb.Nn);
         }
-        double vf = 1.0 / piv, wf = prod / piv;
         if (first) vf = vl = 0.0;                 // no left / right neighbour
         if (last) wf = wl = 0.0;
         const double *mi = msg_in(p);
@@ -183,89 +258,50 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
     }
 }
 
-// A_p x = g + e_first x_left + e_last x_right; the forward sweep leaves d'_t / m_t in x and 1 / m_t in qinv
-__global__ void __launch_bounds__(256) k_tri_final(TriGeom g, const double *__restrict__ back, double *__restrict__ x,
-                                                    double *__restrict__ qinv) {
+// A_p x = g + e_first x_left + e_last x_right by the scaled sweeps above: forward D_t = g_t N_t + rho D_{t-1} (no division),
+// backward x_t = rho (D_t + N_t x_{t+1}) / N_{t+1} (one fast division per row), N_t of the backward walk from the powers.
+// Generic slab length: D_t is parked in x between the sweeps (two reads and two writes of the slab).
+__global__ void __launch_bounds__(256) k_tri_final(TriGeom g, const double *__restrict__ back, double *__restrict__ x) {
     const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
     if (m >= g.plane) return;
-    const i64 n = g.ntl;
+    const int n = (int)g.ntl;
     const int j = tri_owner(g.pc, m, g.plane);
     const i64 off = tri_msg_off(g.pc, j), w = g.pc.cut[j + 1] - g.pc.cut[j];
     if (m == 0) {
-        for (i64 t = 0; t < n; ++t) x[g.plane * t] = back[off + 2 * w + t];
+        for (int t = 0; t < n; ++t) x[g.plane * t] = back[off + 2 * w + t];
         return;
     }
-    const double ap = tri_aprime(g, m);
+    const TriCoef c = tri_coef(tri_aprime(g, m));
+    const bool first = g.first != 0, last = g.last != 0;
     const double sc = 1.0 / (g.kscale * g.beta);
     const double xl = back[off + (m - g.pc.cut[j])], xr = back[off + w + (m - g.pc.cut[j])];
-    double piv = tri_delta(ap, 0, n, g.first, g.last);
-    double d = x[m] * sc + xl + ((n == 1) ? xr : 0.0);
-    double inv = 1.0 / piv;
-    x[m] = d * inv;
-    qinv[m] = inv;
-    for (i64 t = 1; t < n; ++t) {
+    const TriSeq sf = tri_seq(c, first, n);
+    double N = tri_n0(c, first), N1 = N, D = 0.0;
+    for (int t = 0; t < n; ++t) {
         double gt = x[m + g.plane * t] * sc;
+        if (t == 0) gt += xl;
         if (t == n - 1) gt += xr;
-        d = gt + d * inv;
-        piv = tri_delta(ap, t, n, g.first, g.last) - inv;
-        inv = 1.0 / piv;
-        x[m + g.plane * t] = d * inv;
-        qinv[m + g.plane * t] = inv;
+        D = gt * N + c.rho * D;
+        x[m + g.plane * t] = D;
+        N1 = N;
+        N = c.n0d + c.rho2 * N;
     }
-    double xn = x[m + g.plane * (n - 1)];
-    for (i64 t = n - 2; t >= 0; --t) {
-        xn = x[m + g.plane * t] + qinv[m + g.plane * t] * xn;
+    double xn = tri_last(c, D, N1, N, last);
+    x[m + g.plane * (n - 1)] = xn;
+    const double sgn = first ? 1.0 : -1.0;
+    double P = (sf.jsave == n - 1) ? sf.psave : 0.0, Nt1 = N1;      // N_{t+1} of the row below
+    for (int t = n - 2; t >= 0; --t) {
+        if (t == sf.jsave) P = sf.psave;
+        else if (t < sf.jsave) P *= c.r2;
+        const double Nt = 1.0 + sgn * P;
+        xn = tri_div(c.rho * (x[m + g.plane * t] + Nt * xn), Nt1);
         x[m + g.plane * t] = xn;
+        Nt1 = Nt;
     }
 }
 
-
-// Register-resident flavours for short slabs (ntl <= NTL): the column of a mode is read ONCE into registers, both
-// eliminations (k_tri_local) resp. the whole Thomas solve (k_tri_final) run there, and the result is written once --
-// 1 and 2 passes over the slab instead of 2 and 6.  Same operations in the same order as the kernels above.
-template <int NTL>
-__global__ void __launch_bounds__(256) k_tri_local_reg(TriGeom g, const double *__restrict__ r, double *__restrict__ send) {
-    const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (m >= g.plane) return;
-    const double ap = tri_aprime(g, m);
-    const double sc = 1.0 / (g.kscale * g.beta);
-    const int n = (int)g.ntl;
-    double G[NTL];
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) G[t] = (t < n) ? r[m + g.plane * t] * sc : 0.0;
-    double piv = tri_delta(ap, 0, n, g.first, g.last), d = G[0];
-#pragma unroll
-    for (int t = 1; t < NTL; ++t) {
-        if (t < n) {
-            const double inv = 1.0 / piv;
-            d = G[t] + d * inv;
-            piv = tri_delta(ap, t, n, g.first, g.last) - inv;
-        }
-    }
-    const double Gl = d / piv;
-#pragma unroll
-    for (int t = NTL - 1; t >= 0; --t) {
-        if (t == n - 1) {
-            piv = tri_delta(ap, t, n, g.first, g.last);
-            d = G[t];
-        } else if (t < n - 1) {
-            const double inv = 1.0 / piv;
-            d = G[t] + d * inv;
-            piv = tri_delta(ap, t, n, g.first, g.last) - inv;
-        }
-    }
-    const double Gf = d / piv;
-    const int j = tri_owner(g.pc, m, g.plane);
-    const i64 off = tri_msg_off(g.pc, j), w = g.pc.cut[j + 1] - g.pc.cut[j];
-    send[off + (m - g.pc.cut[j])] = Gf;
-    send[off + w + (m - g.pc.cut[j])] = Gl;
-    if (m == 0) {
-#pragma unroll
-        for (int t = 0; t < NTL; ++t)
-            if (t < n) send[off + 2 * w + t] = G[t];
-    }
-}
-
+// Register-resident flavour for short slabs (ntl <= NTL): the column of a mode is read ONCE into registers, both sweeps
+// run there, and the result is written once -- one read and one write of the slab.
 template <int NTL>
 __global__ void __launch_bounds__(256) k_tri_final_reg(TriGeom g, const double *__restrict__ back, double *__restrict__ x) {
     const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -277,38 +313,41 @@ __global__ void __launch_bounds__(256) k_tri_final_reg(TriGeom g, const double *
         for (int t = 0; t < n; ++t) x[g.plane * t] = back[off + 2 * w + t];
         return;
     }
-    const double ap = tri_aprime(g, m);
+    const TriCoef c = tri_coef(tri_aprime(g, m));
+    const bool first = g.first != 0, last = g.last != 0;
     const double sc = 1.0 / (g.kscale * g.beta);
     const double xl = back[off + (m - g.pc.cut[j])], xr = back[off + w + (m - g.pc.cut[j])];
-    double X[NTL], Q[NTL];
+    double X[NTL];
 #pragma unroll
     for (int t = 0; t < NTL; ++t) X[t] = (t < n) ? x[m + g.plane * t] : 0.0;
-    double piv = tri_delta(ap, 0, n, g.first, g.last);
-    double d = X[0] * sc + xl + ((n == 1) ? xr : 0.0);
-    double inv = 1.0 / piv;
-    X[0] = d * inv;
-    Q[0] = inv;
+    const TriSeq sf = tri_seq(c, first, n);
+    double N = tri_n0(c, first), N1 = N, D = 0.0;
 #pragma unroll
-    for (int t = 1; t < NTL; ++t) {
-        Q[t] = 0.0;
+    for (int t = 0; t < NTL; ++t) {
         if (t < n) {
             double gt = X[t] * sc;
+            if (t == 0) gt += xl;
             if (t == n - 1) gt += xr;
-            d = gt + d * inv;
-            piv = tri_delta(ap, t, n, g.first, g.last) - inv;
-            inv = 1.0 / piv;
-            X[t] = d * inv;
-            Q[t] = inv;
+            D = gt * N + c.rho * D;
+            X[t] = D;
+            N1 = N;
+            N = c.n0d + c.rho2 * N;
         }
     }
-    double xn = 0.0;
+    double xn = tri_last(c, D, N1, N, last);
+    const double sgn = first ? 1.0 : -1.0;
+    double P = (sf.jsave == n - 1) ? sf.psave : 0.0, Nt1 = N1;
 #pragma unroll
     for (int t = NTL - 1; t >= 0; --t) {
         if (t == n - 1) {
-            xn = X[t];
-        } else if (t < n - 1) {
-            xn = X[t] + Q[t] * xn;
             X[t] = xn;
+        } else if (t < n - 1) {
+            if (t == sf.jsave) P = sf.psave;
+            else if (t < sf.jsave) P *= c.r2;
+            const double Nt = 1.0 + sgn * P;
+            xn = tri_div(c.rho * (X[t] + Nt * xn), Nt1);
+            X[t] = xn;
+            Nt1 = Nt;
         }
     }
 #pragma unroll
@@ -335,11 +374,7 @@ int launch_tri_local(const Grid &g, i64 nt, double kscale, const double *cy, con
                      const double *r, double *send, hipStream_t st) {
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
     const dim3 grid((unsigned)((g.plane + 255) / 256));
-    const int rw = tri_reg_width(g.ntl);
-    if (rw == 16) DS_KLAUNCH(k_tri_local_reg<16>, grid, dim3(256), 0, st, t, r, send);
-    else if (rw == 32) DS_KLAUNCH(k_tri_local_reg<32>, grid, dim3(256), 0, st, t, r, send);
-    else if (rw == 64) DS_KLAUNCH(k_tri_local_reg<64>, grid, dim3(256), 0, st, t, r, send);
-    else DS_KLAUNCH(k_tri_local, grid, dim3(256), 0, st, t, r, send);
+    DS_KLAUNCH(k_tri_local, grid, dim3(256), 0, st, t, r, send);
     DS_HIP(hipGetLastError());
     return 0;
 }
@@ -371,7 +406,8 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
     if (rw == 16) DS_KLAUNCH(k_tri_final_reg<16>, grid, dim3(256), 0, st, t, back, x);
     else if (rw == 32) DS_KLAUNCH(k_tri_final_reg<32>, grid, dim3(256), 0, st, t, back, x);
     else if (rw == 64) DS_KLAUNCH(k_tri_final_reg<64>, grid, dim3(256), 0, st, t, back, x);
-    else DS_KLAUNCH(k_tri_final, grid, dim3(256), 0, st, t, back, x, qinv);
+    else DS_KLAUNCH(k_tri_final, grid, dim3(256), 0, st, t, back, x);
+    (void)qinv;
     DS_HIP(hipGetLastError());
     return 0;
 }
