@@ -221,6 +221,9 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
                        hipStream_t st, const double *own_recv = nullptr, double *own_back = nullptr);
 int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
                      const double *back, double *x, double *qinv, hipStream_t st);
+// the SINGLE slab's t-axis solve by the same elimination, in place on x = [g.plane][nt] (no transform along t; any nt <= 512)
+bool tsolve_tri_supported(i64 nt);
+int launch_tsolve_tri(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, double *x, hipStream_t st);
 // up to DS_MAX_WORLD messages copied by ONE launch on the receiving slab's stream: message m = count[m] doubles from
 // src[m] (this or a peer device) to dst[m] -- the exchanges between the slabs of one process (one launch per receiver
 // instead of one event-ordered copy per message)

@@ -1314,7 +1314,12 @@ int Solver::poisson_all(const PhiHooks *hooks) {
         if (!multi()) {
             // the single slab: rows may be pitched (common.h), the (y, x) columns of a layer are ny lines in each of nx rows
             const Grid &g = s.g;
-            if (tp2) {
+            if (tri_tsolve && tsolve_tri_supported(nt) && !dct_plan_is_pow2(s.res->pt)) {
+                // no transform along t: the (ky, kx) modes are tridiagonal systems in t (tri.hip: k_tsolve_single) -- every
+                // length but the powers of two, whose pipelined transform pass is faster (0.56 vs 0.62 ms at nt = 128);
+                // DOTSOCP_TSOLVE=dct: the transform passes below for every length
+                DS_CHECK(launch_tsolve_tri(g, nt, D * D, s.res->cy, s.res->cx, p, s.st));
+            } else if (tp2) {
                 DS_CHECK(launch_dct_t_solve(s.res->pt, p, p, ny, ny * nx, 0, ny * nx, nt, D * D, s.res->cy, s.res->cx, s.res->ct, s.st, g.py));
             } else {
                 DS_CHECK(launch_dct_axis(s.res->pt, p, p2, g.ny, g.nx, nt, 2, 0, s.st, g.py));

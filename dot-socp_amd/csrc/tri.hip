@@ -81,28 +81,65 @@ __device__ __forceinline__ double tri_div(double x, double n) {
     const double q = x * r;
     return __builtin_fma(__builtin_fma(-n, q, x), r, q);
 }
-// The sequence N_j, j = 0 .. n, of a sweep that starts on a boundary row (bnd) or not: its last two members, and what a
-// DOWNWARD walk through the powers rho^(2j+e) needs to stay clear of underflow: above `jsave` the power is below 1e-20
-// (N_j = 1 to the last bit), at jsave it is `psave`, below it grows by r^2 per step.
-struct TriSeq {
-    int jsave;
-    double psave, N1, Nn;              // N_{n-1}, N_n
+// N_0, N_{n-1}, N_n of the sweep over n rows that starts on a boundary row (bnd: N_j = 1 + rho^(2j+1)) or not
+// (N_j = 1 - rho^(2j+2)); rn1 = rho^(n-1).  s, pe: N_j = 1 + s pe rho^(2j).
+struct TriEnds {
+    double N0, N1, Nn, s, pe;
 };
-__device__ __forceinline__ TriSeq tri_seq(const TriCoef &c, bool bnd, int n) {
-    TriSeq w{-1, 0.0, 0.0, 0.0};
-    double P = bnd ? c.rho : c.rho2, N = tri_n0(c, bnd);
-    for (int j = 0; j < n; ++j) {
-        if (P >= 1e-20) { w.jsave = j; w.psave = P; }
-        P *= c.rho2;
-        if (j + 1 < n) N = c.n0d + c.rho2 * N;
+__device__ __forceinline__ TriEnds tri_ends(const TriCoef &c, bool bnd, int n, double rn1) {
+    TriEnds e;
+    e.s = bnd ? 1.0 : -1.0;
+    e.pe = bnd ? c.rho : c.rho2;
+    e.N0 = tri_n0(c, bnd);
+    e.N1 = (n == 1) ? e.N0 : 1.0 + e.s * ((rn1 * rn1) * e.pe);
+    e.Nn = c.n0d + c.rho2 * e.N1;
+    return e;
+}
+__device__ __forceinline__ double tri_powi(double x, int k) {
+    double r = 1.0;
+    while (k > 0) {
+        if (k & 1) r *= x;
+        x *= x;
+        k >>= 1;
     }
-    w.N1 = N;
-    w.Nn = c.n0d + c.rho2 * N;
-    return w;
+    return r;
 }
 // the last unknown of a sweep over n rows from its D_{n-1}; bnd: the sweep ENDS on a global boundary row
 __device__ __forceinline__ double tri_last(const TriCoef &c, double D, double N1, double Nn, bool bnd) {
     return bnd ? tri_div(D, c.r * Nn - N1) : tri_div(c.rho * D, Nn);
+}
+// Both sweeps of a column come out of two running sums, H_t = g_t + rho H_{t-1} and G_t = sum_{s <= t} rho^s g_s:
+//     D_t = sum_{s <= t} rho^(t-s) N_s g_s = H_t + s_f pe_f rho^t G_t            (front sweep, kept per row by k_tri_final)
+//     F   = sum_t rho^t N'_{n-1-t} g_t     = G_{n-1} + s_b pe_b rho^(n-1) H_{n-1}  (back sweep, as a weighted sum)
+// -- no power ever has to be walked downwards from a value that may have underflowed.
+// first / last entries of A_p^-1 e_first (vf, vl) and A_p^-1 e_last (wf, wl) of a block of n rows:
+// prod_{s < n-1} 1 / piv_s = rho^(n-1) N_0 / N_{n-1}, 1 / piv_{n-1} = rho N_{n-1} / N_n (boundary end: N_{n-1} / (r N_n - N_{n-1}))
+struct TriSpike {
+    double vf, vl, wf, wl;
+};
+__device__ __forceinline__ TriSpike tri_spike(const TriCoef &c, int n, bool first, bool last) {
+    const double rn1 = tri_powi(c.rho, n - 1);
+    const TriEnds f = tri_ends(c, first, n, rn1), b = tri_ends(c, last, n, rn1);
+    TriSpike k;
+    if (last) {
+        const double den = c.r * f.Nn - f.N1;
+        k.vl = tri_div(rn1 * f.N0, den);
+        k.wl = tri_div(f.N1, den);
+    } else {
+        k.vl = tri_div((rn1 * c.rho) * f.N0, f.Nn);
+        k.wl = tri_div(c.rho * f.N1, f.Nn);
+    }
+    if (first) {
+        const double den = c.r * b.Nn - b.N1;
+        k.wf = tri_div(rn1 * b.N0, den);
+        k.vf = tri_div(b.N1, den);
+    } else {
+        k.wf = tri_div((rn1 * c.rho) * b.N0, b.Nn);
+        k.vf = tri_div(c.rho * b.N1, b.Nn);
+    }
+    if (first) k.vf = k.vl = 0.0;                 // no left / right neighbour
+    if (last) k.wf = k.wl = 0.0;
+    return k;
 }
 
 // One ascending pass over the column of a mode: both eliminations at once, nothing kept (any slab length)
@@ -121,32 +158,25 @@ __global__ void __launch_bounds__(256) k_tri_local(TriGeom g, const double *__re
     }
     const TriCoef c = tri_coef(tri_aprime(g, m));
     const bool first = g.first != 0, last = g.last != 0;
-    // from the front: D_t = g_t N_t + rho D_{t-1}; from the back, as a weighted sum: F = sum_t rho^t N'_{n-1-t} g_t
-    const TriSeq sb = tri_seq(c, last, n);        // the reversed column starts on the slab's LAST row
-    const double sgn = last ? 1.0 : -1.0;
-    double N = tri_n0(c, first), N1 = N, D = 0.0, F = 0.0, pw = 1.0, Pb = 0.0;
-    constexpr int U = 4;
+    double H = 0.0, G = 0.0, pw = 1.0;
+    constexpr int U = 8;
     for (int t0 = 0; t0 < n; t0 += U) {
         double gv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) gv[u] = (t0 + u < n) ? r[m + g.plane * (t0 + u)] * sc : 0.0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = t0 + u;
-            if (t < n) {
-                D = gv[u] * N + c.rho * D;
-                N1 = N;
-                N = c.n0d + c.rho2 * N;                    // N_{t+1}
-                const int jb = n - 1 - t;
-                if (jb == sb.jsave) Pb = sb.psave;
-                else if (jb < sb.jsave) Pb *= c.r2;
-                F += (pw * (1.0 + sgn * Pb)) * gv[u];
-                pw *= c.rho;
+            if (t0 + u < n) {
+                H = gv[u] + c.rho * H;
+                G += pw * gv[u];
+                if (t0 + u + 1 < n) pw *= c.rho;           // ends as rho^(n-1)
             }
         }
     }
-    send[off + (m - g.pc.cut[j])] = tri_last(c, F, sb.N1, sb.Nn, first);      // first entry of A^-1 g
-    send[off + w + (m - g.pc.cut[j])] = tri_last(c, D, N1, N, last);          // last entry
+    const TriEnds f = tri_ends(c, first, n, pw), b = tri_ends(c, last, n, pw);
+    const double D = H + ((f.s * f.pe) * pw) * G, F = G + ((b.s * b.pe) * pw) * H;
+    send[off + (m - g.pc.cut[j])] = tri_last(c, F, b.N1, b.Nn, first);        // first entry of A^-1 g
+    send[off + w + (m - g.pc.cut[j])] = tri_last(c, D, f.N1, f.Nn, last);     // last entry
 }
 
 struct TriReduced {
@@ -204,32 +234,8 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
         if (p >= q.P) break;
-        const int n = (int)q.slab_n[p];
-        const bool first = (p == 0), last = (p == q.P - 1);
-        // first / last entries of A_p^{-1} e_first (vf, vl) and A_p^{-1} e_last (wf, wl) in closed form:
-        // prod_{s < n-1} 1 / piv_s = rho^(n-1) N_0 / N_{n-1}, 1 / piv_{n-1} = rho N_{n-1} / N_n (boundary end: N_{n-1} / (r N_n - N_{n-1}))
-        const TriSeq sf = tri_seq(c, first, n), sb = tri_seq(c, last, n);
-        double rn1 = 1.0;                                  // rho^(n-1)
-        for (int t = 1; t < n; ++t) rn1 *= c.rho;
-        double vl, wl, vf, wf;
-        if (last) {
-            const double den = c.r * sf.Nn - sf.N1;
-            vl = tri_div(rn1 * tri_n0(c, first), den);
-            wl = tri_div(sf.N1, den);
-        } else {
-            vl = tri_div((rn1 * c.rho) * tri_n0(c, first), sf.Nn);
-            wl = tri_div(c.rho * sf.N1, sf.Nn);
-        }
-        if (first) {
-            const double den = c.r * sb.Nn - sb.N1;
-            wf = tri_div(rn1 * tri_n0(c, last), den);
-            vf = tri_div(sb.N1, den);
-        } else {
-            wf = tri_div((rn1 * c.rho) * tri_n0(c, last), sb.Nn);
-            vf = tri_div(c.rho * sb.N1, sb.Nn);
-        }
-        if (first) vf = vl = 0.0;                 // no left / right neighbour
-        if (last) wf = wl = 0.0;
+        const TriSpike k = tri_spike(c, (int)q.slab_n[p], p == 0, p == q.P - 1);
+        const double vf = k.vf, vl = k.vl, wf = k.wf, wl = k.wl;
         const double *mi = msg_in(p);
         const double Gf = mi[i], Gl = mi[q.nl + i];
         // unknowns F_p (first value of slab p), L_p (last value):  F_p = Gf + vf L_{p-1} + wf F_{p+1},  L_p = Gl + vl L_{p-1} + wl F_{p+1}
@@ -258,8 +264,8 @@ __global__ void __launch_bounds__(128) k_tri_reduced(TriGeom g, TriReduced q, co
     }
 }
 
-// A_p x = g + e_first x_left + e_last x_right by the scaled sweeps above: forward D_t = g_t N_t + rho D_{t-1} (no division),
-// backward x_t = rho (D_t + N_t x_{t+1}) / N_{t+1} (one fast division per row), N_t of the backward walk from the powers.
+// A_p x = g + e_first x_left + e_last x_right: forward D_t from the two running sums (no division), backward
+// x_t = rho (D_t + N_t x_{t+1}) / N_{t+1} (one fast division per row), N_t = 1 + s pe rho^(2t) from rho^t walked back up.
 // Generic slab length: D_t is parked in x between the sweeps (two reads and two writes of the slab).
 __global__ void __launch_bounds__(256) k_tri_final(TriGeom g, const double *__restrict__ back, double *__restrict__ x) {
     const i64 m = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -275,25 +281,25 @@ __global__ void __launch_bounds__(256) k_tri_final(TriGeom g, const double *__re
     const bool first = g.first != 0, last = g.last != 0;
     const double sc = 1.0 / (g.kscale * g.beta);
     const double xl = back[off + (m - g.pc.cut[j])], xr = back[off + w + (m - g.pc.cut[j])];
-    const TriSeq sf = tri_seq(c, first, n);
-    double N = tri_n0(c, first), N1 = N, D = 0.0;
+    const double spe = first ? c.rho : -c.rho2;                     // s pe of the front sequence
+    double H = 0.0, G = 0.0, pw = 1.0, D = 0.0;
     for (int t = 0; t < n; ++t) {
         double gt = x[m + g.plane * t] * sc;
         if (t == 0) gt += xl;
         if (t == n - 1) gt += xr;
-        D = gt * N + c.rho * D;
+        H = gt + c.rho * H;
+        G += pw * gt;
+        D = H + (spe * pw) * G;
         x[m + g.plane * t] = D;
-        N1 = N;
-        N = c.n0d + c.rho2 * N;
+        if (t + 1 < n) pw *= c.rho;
     }
-    double xn = tri_last(c, D, N1, N, last);
+    const TriEnds f = tri_ends(c, first, n, pw);
+    double xn = tri_last(c, D, f.N1, f.Nn, last);
     x[m + g.plane * (n - 1)] = xn;
-    const double sgn = first ? 1.0 : -1.0;
-    double P = (sf.jsave == n - 1) ? sf.psave : 0.0, Nt1 = N1;      // N_{t+1} of the row below
+    double Nt1 = f.N1;
     for (int t = n - 2; t >= 0; --t) {
-        if (t == sf.jsave) P = sf.psave;
-        else if (t < sf.jsave) P *= c.r2;
-        const double Nt = 1.0 + sgn * P;
+        pw *= c.r;
+        const double Nt = (t == 0) ? f.N0 : 1.0 + spe * (pw * pw);
         xn = tri_div(c.rho * (x[m + g.plane * t] + Nt * xn), Nt1);
         x[m + g.plane * t] = xn;
         Nt1 = Nt;
@@ -320,31 +326,31 @@ __global__ void __launch_bounds__(256) k_tri_final_reg(TriGeom g, const double *
     double X[NTL];
 #pragma unroll
     for (int t = 0; t < NTL; ++t) X[t] = (t < n) ? x[m + g.plane * t] : 0.0;
-    const TriSeq sf = tri_seq(c, first, n);
-    double N = tri_n0(c, first), N1 = N, D = 0.0;
+    const double spe = first ? c.rho : -c.rho2;
+    double H = 0.0, G = 0.0, pw = 1.0, D = 0.0;
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         if (t < n) {
             double gt = X[t] * sc;
             if (t == 0) gt += xl;
             if (t == n - 1) gt += xr;
-            D = gt * N + c.rho * D;
+            H = gt + c.rho * H;
+            G += pw * gt;
+            D = H + (spe * pw) * G;
             X[t] = D;
-            N1 = N;
-            N = c.n0d + c.rho2 * N;
+            if (t + 1 < n) pw *= c.rho;
         }
     }
-    double xn = tri_last(c, D, N1, N, last);
-    const double sgn = first ? 1.0 : -1.0;
-    double P = (sf.jsave == n - 1) ? sf.psave : 0.0, Nt1 = N1;
+    const TriEnds f = tri_ends(c, first, n, pw);
+    double xn = tri_last(c, D, f.N1, f.Nn, last);
+    double Nt1 = f.N1;
 #pragma unroll
     for (int t = NTL - 1; t >= 0; --t) {
         if (t == n - 1) {
             X[t] = xn;
         } else if (t < n - 1) {
-            if (t == sf.jsave) P = sf.psave;
-            else if (t < sf.jsave) P *= c.r2;
-            const double Nt = 1.0 + sgn * P;
+            pw *= c.r;
+            const double Nt = (t == 0) ? f.N0 : 1.0 + spe * (pw * pw);
             xn = tri_div(c.rho * (X[t] + Nt * xn), Nt1);
             X[t] = xn;
             Nt1 = Nt;
@@ -408,6 +414,195 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
     else if (rw == 64) DS_KLAUNCH(k_tri_final_reg<64>, grid, dim3(256), 0, st, t, back, x);
     else DS_KLAUNCH(k_tri_final, grid, dim3(256), 0, st, t, back, x);
     (void)qinv;
+    DS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The single slab's t-axis solve by the same elimination (round 4): phi^ = idct_t(dct_t(r^) ./ kernel) IS the solution of
+// D^2 ((CY + CX) I + T) phi^ = r^ per (ky, kx) mode, so the t axis needs no transform at all -- for ANY nt.  A workgroup of
+// NSUB wavefronts owns 64 consecutive modes (one coalesced 512-byte segment per time layer); wavefront w holds the rows
+// [t_w, t_{w+1}) of those modes in registers (R = 32 at nt = 128 / 129: ~110 registers, four waves per SIMD) and the NSUB
+// pieces of a column are coupled exactly like time slabs: scaled sweep from the front (D_t kept in the registers) and the
+// weighted sum from the back -> first / last entry of A_p^-1 g_p, exchanged through LDS -> every wave solves the small
+// reduced system of its modes (closed-form coefficients) -> backward sweep with the neighbours' interface values
+// (D_t is linear in the right-hand side: the left value enters as xl N_0 rho^t) -> one write.  One read and one write of
+// the array, ~20 flops per entry: bound by HBM where the fused transform pass (two FFTs, seven barriers per tile) is
+// bound by its own LDS / VALU chain.  Measured: 0.62 ms at 1024 x 1024 x 128 against 0.56 ms for the pipelined transform pass
+// (which therefore stays for the power-of-two lengths), 0.66 ms at 1025 x 1025 x 129 against 0.86 ms for the prime-factor pass,
+// and no dense t-axis product at all for the other lengths: the default whenever nt is no power of two (Solver::poisson_all).
+// The singular (0, 0) mode: its column is parked in LDS, one thread runs k_tri_reduced's recurrence on it.
+template <int R, int NSUB>
+__global__ void __launch_bounds__(64 * NSUB) k_tsolve_single(TriGeom g, i64 nt, double *__restrict__ x) {
+    // per piece and mode: first / last entry of A_p^-1 g_p and the piece's four spike values; then the interface values
+    __shared__ double ex[NSUB][6][64];
+    __shared__ double sw[NSUB][4][64];                 // the reduced sweep's A, B, al, ga (wave 0)
+    __shared__ double zcol[NSUB * R];                  // the singular mode's column (workgroup 0 only)
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 m = (i64)blockIdx.x * 64 + lane;
+    const bool ok = m < g.plane;
+    const i64 mc = ok ? m : 0;
+    // rows of piece p: as evenly as possible (dotsocp_slab_range_impl's rule)
+    const int base = (int)(nt / NSUB), rem = (int)(nt % NSUB);
+    auto t_begin = [&](int p) { return p * base + (p < rem ? p : rem); };
+    const int t0 = t_begin(w), n = t_begin(w + 1) - t0;
+    const bool first = (w == 0), last = (w == NSUB - 1);
+    const double sc = 1.0 / (g.kscale * g.beta);
+    double X[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) X[t] = (t < n) ? x[mc + g.plane * (t0 + t)] * sc : 0.0;
+    const bool zero = (m == 0);
+    const TriCoef c = tri_coef(zero ? 1.0 : tri_aprime(g, mc));      // (the singular mode takes its own path below)
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+            if (t < n) zcol[t0 + t] = X[t];
+    }
+    // ---- local eliminations (the two running sums, see above) ----
+    const double spe = first ? c.rho : -c.rho2;
+    double H = 0.0, G = 0.0, pw = 1.0, D = 0.0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        if (t < n) {
+            const double gt = X[t];
+            H = gt + c.rho * H;
+            G += pw * gt;
+            D = H + (spe * pw) * G;
+            X[t] = D;
+            if (t + 1 < n) pw *= c.rho;                            // ends as rho^(n-1)
+        }
+    }
+    const TriEnds f = tri_ends(c, first, n, pw), b = tri_ends(c, last, n, pw);
+    if (NSUB > 1) {
+        ex[w][0][lane] = tri_last(c, G + ((b.s * b.pe) * pw) * H, b.N1, b.Nn, first);
+        ex[w][1][lane] = tri_last(c, D, f.N1, f.Nn, last);
+        // the piece's spike values (tri_spike, from the ends already at hand)
+        double vf, vl, wf, wl;
+        if (last) {
+            const double den = c.r * f.Nn - f.N1;
+            vl = tri_div(pw * f.N0, den);
+            wl = tri_div(f.N1, den);
+        } else {
+            vl = tri_div((pw * c.rho) * f.N0, f.Nn);
+            wl = tri_div(c.rho * f.N1, f.Nn);
+        }
+        if (first) {
+            const double den = c.r * b.Nn - b.N1;
+            wf = tri_div(pw * b.N0, den);
+            vf = tri_div(b.N1, den);
+        } else {
+            wf = tri_div((pw * c.rho) * b.N0, b.Nn);
+            vf = tri_div(c.rho * b.N1, b.Nn);
+        }
+        ex[w][2][lane] = first ? 0.0 : vf;
+        ex[w][3][lane] = first ? 0.0 : vl;
+        ex[w][4][lane] = last ? 0.0 : wf;
+        ex[w][5][lane] = last ? 0.0 : wl;
+    }
+    __syncthreads();
+    // ---- reduced system of the NSUB pieces (k_tri_reduced's sweep), by wave 0 for the workgroup's 64 modes ----
+    double xl = 0.0, xr = 0.0;
+    if (NSUB > 1) {
+        if (w == 0) {
+#pragma unroll 1
+            for (int p = 0; p < NSUB; ++p) {
+                const double Gf = ex[p][0][lane], Gl = ex[p][1][lane];
+                const double vf = ex[p][2][lane], vl = ex[p][3][lane], wf = ex[p][4][lane], wl = ex[p][5][lane];
+                double A, B, al, ga;
+                if (p == 0) {
+                    A = Gf; B = wf; al = Gl; ga = wl;
+                } else {
+                    const double alp = sw[p - 1][2][lane], gap = sw[p - 1][3][lane];
+                    const double den = 1.0 - vf * gap;
+                    A = (Gf + vf * alp) / den;
+                    B = wf / den;
+                    al = Gl + vl * (alp + gap * A);
+                    ga = wl + vl * gap * B;
+                }
+                sw[p][0][lane] = A; sw[p][1][lane] = B; sw[p][2][lane] = al; sw[p][3][lane] = ga;
+            }
+            double Fnext = 0.0;
+#pragma unroll 1
+            for (int p = NSUB - 1; p >= 0; --p) {
+                const double Fp = sw[p][0][lane] + sw[p][1][lane] * Fnext;
+                const double Lprev = (p > 0) ? sw[p - 1][2][lane] + sw[p - 1][3][lane] * Fp : 0.0;
+                ex[p][0][lane] = Lprev;                            // the piece's left / right interface values
+                ex[p][1][lane] = Fnext;
+                Fnext = Fp;
+            }
+        }
+        __syncthreads();
+        xl = ex[w][0][lane];
+        xr = ex[w][1][lane];
+    }
+    // ---- the singular mode ----
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            // T x = g - mean(g) by recurrence from x_0 = 0, then zero mean, plus beta * mean(g) (k_tri_reduced)
+            double sum = 0.0;
+            for (i64 t = 0; t < nt; ++t) sum += zcol[t];
+            const double gbar = sum / (double)nt;
+            double xm = 0.0, xc = 0.0, acc = 0.0;
+            for (i64 t = 0; t < nt; ++t) {
+                const double gt = zcol[t] - gbar;
+                zcol[t] = xc;
+                acc += xc;
+                const double xn = (t == 0) ? xc - gt : 2.0 * xc - xm - gt;
+                xm = xc;
+                xc = xn;
+            }
+            const double shift = g.beta * gbar - acc / (double)nt;
+            for (i64 t = 0; t < nt; ++t) zcol[t] += shift;
+        }
+        __syncthreads();
+    }
+    // ---- backward sweep with the interface values ----
+    const double cl = xl * f.N0;                                   // D_t gains cl rho^t; D_{n-1} also xr N_{n-1}
+    double xn = tri_last(c, (D + cl * pw) + xr * f.N1, f.N1, f.Nn, last);
+    double Nt1 = f.N1;
+#pragma unroll
+    for (int t = R - 1; t >= 0; --t) {
+        if (t == n - 1) {
+            X[t] = xn;
+        } else if (t < n - 1) {
+            pw *= c.r;                                             // rho^t
+            const double Nt = (t == 0) ? f.N0 : 1.0 + spe * (pw * pw);
+            xn = tri_div(c.rho * ((X[t] + cl * pw) + Nt * xn), Nt1);
+            X[t] = xn;
+            Nt1 = Nt;
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+            if (t < n) x[m + g.plane * (t0 + t)] = zero ? zcol[t0 + t] : X[t];
+    }
+}
+
+bool tsolve_tri_supported(i64 nt) { return nt >= 2 && nt <= 512; }
+
+// in place on x: [plane][nt] with plane = py * nx doubles per layer (pad entries of a row are modes of their own: zeros)
+int launch_tsolve_tri(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, double *x, hipStream_t st) {
+    PencilCuts pc{};
+    pc.world = 1;
+    pc.cut[0] = 0;
+    pc.cut[1] = g.plane;
+    const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
+    const dim3 grid((unsigned)((g.plane + 63) / 64));
+#define TSOLVE(RR, NS) DS_KLAUNCH((k_tsolve_single<RR, NS>), grid, dim3(64 * NS), 0, st, t, nt, x)
+    // (measured at nt = 128 / 129, 1024 / 1025-point y and x: 4 waves x 32 rows 0.62 / 0.66 ms, 8 x 16 0.66 / 0.70, 16 x 8 0.97 / 1.02)
+    if (nt <= 8) TSOLVE(8, 1);
+    else if (nt <= 16) TSOLVE(8, 2);
+    else if (nt <= 32) TSOLVE(16, 2);
+    else if (nt <= 64) TSOLVE(16, 4);
+    else if (nt <= 128) TSOLVE(32, 4);
+    else if (nt <= 136) TSOLVE(34, 4);
+    else if (nt <= 256) TSOLVE(32, 8);
+    else if (nt <= 272) TSOLVE(34, 8);
+    else if (nt <= 512) TSOLVE(64, 8);
+    else { set_error("tridiagonal t-solve: nt > 512"); return DOTSOCP_EINVAL; }
+#undef TSOLVE
     DS_HIP(hipGetLastError());
     return 0;
 }
