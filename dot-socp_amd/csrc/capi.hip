@@ -226,7 +226,17 @@ int dotsocp_oper_poisson(double *res, const double *rhs, dotsocp_i64 ny, dotsocp
     DS_CHECK(table(cx, nx));
     DS_CHECK(table(ct, nt));
     DS_HIP(hipMemcpy(da.p, rhs, sizeof(double) * n, hipMemcpyHostToDevice));
-    if (dct_plan_has_tsolve(pl.pt)) {
+    const char *ts = getenv("DOTSOCP_TSOLVE");
+    if (!(ts && strcmp(ts, "dct") == 0) && tsolve_tri_preferred(nt, dct_plan_is_pow2(pl.pt), ny * nx)) {
+        // the sequence of Solver::poisson_all where the t axis is solved as tridiagonal systems (tri.hip): no transform along t
+        Grid g;
+        g.set(ny, nx, nt, 0, nt);
+        DS_CHECK(launch_dct_axis(pl.py, da.p, db.p, ny, nx, nt, 0, 0, nullptr));
+        DS_CHECK(launch_dct_axis(pl.px, db.p, da.p, ny, nx, nt, 1, 0, nullptr));
+        DS_CHECK(launch_tsolve_tri(g, nt, kernelScale, cy.p, cx.p, da.p, nullptr));
+        DS_CHECK(launch_dct_axis(pl.px, da.p, db.p, ny, nx, nt, 1, 1, nullptr));
+        DS_CHECK(launch_dct_axis(pl.py, db.p, da.p, ny, nx, nt, 0, 1, nullptr));
+    } else if (dct_plan_has_tsolve(pl.pt)) {
         // the sequence of Solver::poisson_all: y, x forward, the fused t pass (forward, division, inverse), x, y inverse
         DS_CHECK(launch_dct_axis(pl.py, da.p, db.p, ny, nx, nt, 0, 0, nullptr));
         DS_CHECK(launch_dct_axis(pl.px, db.p, da.p, ny, nx, nt, 1, 0, nullptr));

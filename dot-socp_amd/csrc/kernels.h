@@ -223,6 +223,7 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
                      const double *back, double *x, double *qinv, hipStream_t st);
 // the SINGLE slab's t-axis solve by the same elimination, in place on x = [g.plane][nt] (no transform along t; any nt <= 512)
 bool tsolve_tri_supported(i64 nt);
+bool tsolve_tri_preferred(i64 nt, bool pow2, i64 plane);      // faster than the transform pass(es) along t?
 int launch_tsolve_tri(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, double *x, hipStream_t st);
 // up to DS_MAX_WORLD messages copied by ONE launch on the receiving slab's stream: message m = count[m] doubles from
 // src[m] (this or a peer device) to dst[m] -- the exchanges between the slabs of one process (one launch per receiver

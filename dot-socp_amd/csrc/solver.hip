@@ -1314,9 +1314,8 @@ int Solver::poisson_all(const PhiHooks *hooks) {
         if (!multi()) {
             // the single slab: rows may be pitched (common.h), the (y, x) columns of a layer are ny lines in each of nx rows
             const Grid &g = s.g;
-            if (tri_tsolve && tsolve_tri_supported(nt) && !dct_plan_is_pow2(s.res->pt)) {
-                // no transform along t: the (ky, kx) modes are tridiagonal systems in t (tri.hip: k_tsolve_single) -- every
-                // length but the powers of two, whose pipelined transform pass is faster (0.56 vs 0.62 ms at nt = 128);
+            if (tri_tsolve && tsolve_tri_preferred(nt, dct_plan_is_pow2(s.res->pt), g.plane)) {
+                // no transform along t: the (ky, kx) modes are tridiagonal systems in t (tri.hip: k_tsolve_single / _pipe);
                 // DOTSOCP_TSOLVE=dct: the transform passes below for every length
                 DS_CHECK(launch_tsolve_tri(g, nt, D * D, s.res->cy, s.res->cx, p, s.st));
             } else if (tp2) {

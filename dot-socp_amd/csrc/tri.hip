@@ -18,7 +18,9 @@
 #include "device_utils.h"
 #include "kernels.h"
 
+#include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 namespace dotsocp {
 
@@ -580,7 +582,208 @@ __global__ void __launch_bounds__(64 * NSUB) k_tsolve_single(TriGeom g, i64 nt, 
     }
 }
 
+// The same solve as a PERSISTENT kernel fed by LDS-DMA (the recipe of dct.hip's pipelined passes): a workgroup walks tiles of
+// 64 modes; the rows of the NEXT tile travel into an LDS image [row][mode] by global_load_lds_dwordx4 (no registers) while
+// the current tile is eliminated in registers and stored, so loads are in flight all the time -- the one-tile-per-workgroup
+// kernel above alternates between loading and computing (0.62 ms at nt = 128 where the traffic takes 0.4).  One LDS image:
+// the DMA of tile i + 1 is issued behind the barrier that follows the forward sweep of tile i (every wave has copied its
+// rows to registers by then); it has landed when only the stores issued after it are outstanding (vector-memory operations
+// of a wave complete in issue order) -- counted waits and raw barriers, a fence would drain the counter.
+template <int R, int NSUB>
+__global__ void __launch_bounds__(64 * NSUB) k_tsolve_pipe(TriGeom g, i64 nt, int nTiles, double *__restrict__ x) {
+    extern __shared__ double img[];                    // [nt rounded up to even][64]
+    __shared__ double ex[NSUB][6][64];                 // per piece: Gf, Gl, vf, vl, wf, wl -> xl, xr, A, B, al, ga (in place)
+    __shared__ double zcol[NSUB * R];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int base = (int)(nt / NSUB), rem = (int)(nt % NSUB);
+    auto t_begin = [&](int p) { return p * base + (p < rem ? p : rem); };
+    const int t0 = t_begin(w), n = t_begin(w + 1) - t0;
+    const bool first = (w == 0), last = (w == NSUB - 1);
+    const double sc = 1.0 / (g.kscale * g.beta);
+    const unsigned ldsBase = (unsigned)(uintptr_t)img;
+    const int npairs = (int)((nt + 1) / 2);            // one DMA instruction moves two rows (2 x 512 bytes)
+    // every wave issues the pairs w, w + NSUB, ...; lane l fetches modes 2 (l & 31), +1 of row 2 pair + (l >> 5)
+    auto dma = [&](int tile) {
+        const i64 m0 = (i64)tile * 64;
+        i64 mm = m0 + 2 * (lane & 31);
+        if (mm + 1 >= g.plane) mm = g.plane - 2;       // (plane is even; clamped lanes fetch something valid, never used)
+        for (int pr = w; pr < npairs; pr += NSUB) {
+            int row = 2 * pr + (lane >> 5);
+            if (row >= nt) row = (int)nt - 1;
+            glds16(x + mm + g.plane * row, ldsBase + (unsigned)pr * 1024u);
+        }
+    };
+    int tile = blockIdx.x;
+    const int stride = gridDim.x;
+    if (tile < nTiles) dma(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the waits inside the loop count on the stores of a previous tile)
+    for (; tile < nTiles; tile += stride) {
+        // the tile has landed when nothing but this wave's stores of the previous tile (issued behind its DMA) is outstanding
+        if (n == R) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(R) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(R > 1 ? R - 1 : 0) : "memory");
+        lds_barrier();
+        const i64 m = (i64)tile * 64 + lane;
+        const bool ok = m < g.plane;
+        const i64 mc = ok ? m : 0;
+        double X[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) X[t] = (t < n) ? img[(t0 + t) * 64 + lane] * sc : 0.0;
+        const bool zero = (m == 0);
+        const TriCoef c = tri_coef(zero ? 1.0 : tri_aprime(g, mc));
+        if (tile == 0 && lane == 0) {
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                if (t < n) zcol[t0 + t] = X[t];
+        }
+        const double spe = first ? c.rho : -c.rho2;
+        double H = 0.0, G = 0.0, pw = 1.0, D = 0.0;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            if (t < n) {
+                const double gt = X[t];
+                H = gt + c.rho * H;
+                G += pw * gt;
+                D = H + (spe * pw) * G;
+                X[t] = D;
+                if (t + 1 < n) pw *= c.rho;
+            }
+        }
+        const TriEnds f = tri_ends(c, first, n, pw), b = tri_ends(c, last, n, pw);
+        if (NSUB > 1) {
+            ex[w][0][lane] = tri_last(c, G + ((b.s * b.pe) * pw) * H, b.N1, b.Nn, first);
+            ex[w][1][lane] = tri_last(c, D, f.N1, f.Nn, last);
+            double vf, vl, wf, wl;
+            if (last) {
+                const double den = c.r * f.Nn - f.N1;
+                vl = tri_div(pw * f.N0, den);
+                wl = tri_div(f.N1, den);
+            } else {
+                vl = tri_div((pw * c.rho) * f.N0, f.Nn);
+                wl = tri_div(c.rho * f.N1, f.Nn);
+            }
+            if (first) {
+                const double den = c.r * b.Nn - b.N1;
+                wf = tri_div(pw * b.N0, den);
+                vf = tri_div(b.N1, den);
+            } else {
+                wf = tri_div((pw * c.rho) * b.N0, b.Nn);
+                vf = tri_div(c.rho * b.N1, b.Nn);
+            }
+            ex[w][2][lane] = first ? 0.0 : vf;
+            ex[w][3][lane] = first ? 0.0 : vl;
+            ex[w][4][lane] = last ? 0.0 : wf;
+            ex[w][5][lane] = last ? 0.0 : wl;
+        }
+        lds_barrier();                                 // every wave has its rows in registers: the image is free
+        if (tile + stride < nTiles) dma(tile + stride);
+        double xl = 0.0, xr = 0.0;
+        if (NSUB > 1) {
+            if (w == 0) {
+#pragma unroll 1
+                for (int p = 0; p < NSUB; ++p) {
+                    const double Gf = ex[p][0][lane], Gl = ex[p][1][lane];
+                    const double vf = ex[p][2][lane], vl = ex[p][3][lane], wf = ex[p][4][lane], wl = ex[p][5][lane];
+                    double A, B, al, ga;
+                    if (p == 0) {
+                        A = Gf; B = wf; al = Gl; ga = wl;
+                    } else {
+                        const double alp = ex[p - 1][4][lane], gap = ex[p - 1][5][lane];
+                        const double den = 1.0 - vf * gap;
+                        A = (Gf + vf * alp) / den;
+                        B = wf / den;
+                        al = Gl + vl * (alp + gap * A);
+                        ga = wl + vl * gap * B;
+                    }
+                    ex[p][2][lane] = A; ex[p][3][lane] = B; ex[p][4][lane] = al; ex[p][5][lane] = ga;
+                }
+                double Fnext = 0.0;
+#pragma unroll 1
+                for (int p = NSUB - 1; p >= 0; --p) {
+                    const double Fp = ex[p][2][lane] + ex[p][3][lane] * Fnext;
+                    const double Lprev = (p > 0) ? ex[p - 1][4][lane] + ex[p - 1][5][lane] * Fp : 0.0;
+                    ex[p][0][lane] = Lprev;
+                    ex[p][1][lane] = Fnext;
+                    Fnext = Fp;
+                }
+            }
+            lds_barrier();
+            xl = ex[w][0][lane];
+            xr = ex[w][1][lane];
+        }
+        if (tile == 0) {                               // the singular mode (k_tri_reduced's recurrence)
+            if (threadIdx.x == 0) {
+                double sum = 0.0;
+                for (i64 t = 0; t < nt; ++t) sum += zcol[t];
+                const double gbar = sum / (double)nt;
+                double xm = 0.0, xc = 0.0, acc = 0.0;
+                for (i64 t = 0; t < nt; ++t) {
+                    const double gt = zcol[t] - gbar;
+                    zcol[t] = xc;
+                    acc += xc;
+                    const double xn = (t == 0) ? xc - gt : 2.0 * xc - xm - gt;
+                    xm = xc;
+                    xc = xn;
+                }
+                const double shift = g.beta * gbar - acc / (double)nt;
+                for (i64 t = 0; t < nt; ++t) zcol[t] += shift;
+            }
+            lds_barrier();
+        }
+        const double cl = xl * f.N0;
+        double xn = tri_last(c, (D + cl * pw) + xr * f.N1, f.N1, f.Nn, last);
+        double Nt1 = f.N1;
+#pragma unroll
+        for (int t = R - 1; t >= 0; --t) {
+            if (t == n - 1) {
+                X[t] = xn;
+            } else if (t < n - 1) {
+                pw *= c.r;
+                const double Nt = (t == 0) ? f.N0 : 1.0 + spe * (pw * pw);
+                xn = tri_div(c.rho * ((X[t] + cl * pw) + Nt * xn), Nt1);
+                X[t] = xn;
+                Nt1 = Nt;
+            }
+        }
+        // exactly n stores per wave and tile (the wait at the top counts them): lanes beyond the plane rewrite a valid entry
+        // of their own tile's last mode?  no -- they store nothing: the count is per wave instruction, not per lane
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+            if (t < n) {
+                if (ok) x[m + g.plane * (t0 + t)] = zero ? zcol[t0 + t] : X[t];
+            }
+    }
+}
+
+static int tri_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t pr;
+        cus[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 bool tsolve_tri_supported(i64 nt) { return nt >= 2 && nt <= 512; }
+
+static bool tsolve_pipe_on() {
+    const char *pe = getenv("DOTSOCP_TS_PIPE");        // read per call: the tests switch it inside one process
+    return !(pe && atoi(pe) == 0);
+}
+// the persistent LDS-DMA flavour: grids with enough tiles to keep two workgroups per CU busy for many rounds; its image
+// fits twice into a CU's LDS up to nt = 136
+static bool tsolve_pipe_fits(i64 nt, i64 plane) {
+    return nt > 64 && nt <= 136 && (plane + 63) / 64 >= 16 * (i64)tri_device_cus() && (plane % 2) == 0;
+}
+// Is the tridiagonal solve the faster t-axis solve of a single slab?  Every length without a power-of-two transform pass
+// (prime-factor lengths 0.66 vs 0.86 ms at 1025 x 1025 x 129, and no dense product along t for the rest); powers of two
+// where the pipelined flavour applies (0.51 vs 0.56 ms at 1024 x 1024 x 128; the one-tile-per-workgroup kernel: 0.62).
+bool tsolve_tri_preferred(i64 nt, bool pow2, i64 plane) {
+    if (!tsolve_tri_supported(nt)) return false;
+    return !pow2 || (tsolve_pipe_on() && tsolve_pipe_fits(nt, plane));
+}
 
 // in place on x: [plane][nt] with plane = py * nx doubles per layer (pad entries of a row are modes of their own: zeros)
 int launch_tsolve_tri(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, double *x, hipStream_t st) {
@@ -590,8 +793,30 @@ int launch_tsolve_tri(const Grid &g, i64 nt, double kscale, const double *cy, co
     pc.cut[1] = g.plane;
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
     const dim3 grid((unsigned)((g.plane + 63) / 64));
+    const int nTiles = (int)((g.plane + 63) / 64);
+    const size_t img = (size_t)((nt + 1) / 2) * 2 * 64 * sizeof(double);
+    // persistent LDS-DMA flavour (DOTSOCP_TS_PIPE=0: the one-tile-per-workgroup kernel)
+    const int G = 2 * tri_device_cus();
+    const bool pipe = tsolve_pipe_on() && tsolve_pipe_fits(nt, g.plane);
+    if (pipe) {
+        static std::mutex mu;
+        static unsigned long long done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (dev >= 0 && dev < 64 && !(done & (1ull << dev))) {
+                (void)hipFuncSetAttribute((const void *)(k_tsolve_pipe<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                (void)hipFuncSetAttribute((const void *)(k_tsolve_pipe<34, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                done |= 1ull << dev;
+            }
+        }
+        if (nt <= 128) DS_KLAUNCH((k_tsolve_pipe<32, 4>), dim3((unsigned)G), dim3(256), img, st, t, nt, nTiles, x);
+        else DS_KLAUNCH((k_tsolve_pipe<34, 4>), dim3((unsigned)G), dim3(256), img, st, t, nt, nTiles, x);
+        DS_HIP(hipGetLastError());
+        return 0;
+    }
 #define TSOLVE(RR, NS) DS_KLAUNCH((k_tsolve_single<RR, NS>), grid, dim3(64 * NS), 0, st, t, nt, x)
-    // (measured at nt = 128 / 129, 1024 / 1025-point y and x: 4 waves x 32 rows 0.62 / 0.66 ms, 8 x 16 0.66 / 0.70, 16 x 8 0.97 / 1.02)
     if (nt <= 8) TSOLVE(8, 1);
     else if (nt <= 16) TSOLVE(8, 2);
     else if (nt <= 32) TSOLVE(16, 2);

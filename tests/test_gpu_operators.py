@@ -164,7 +164,12 @@ def test_dctn_many_lines(shape):
                                       (256, 128, 128), (128, 512, 256), (64, 512, 512), (32, 1024, 1024),
                                       (256, 160, 128), (64, 1000, 128),        # tile counts that leave a remainder
                                       # short time axes in the pipelined t pass (tiles of 64 / 32 pairs of columns)
-                                      (512, 512, 32), (256, 1024, 64), (1024, 300, 32)])
+                                      (512, 512, 32), (256, 1024, 64), (1024, 300, 32),
+                                      # the t axis as tridiagonal systems (tri.hip): one tile per workgroup (any nt <= 512 that
+                                      # is no power of two) and the persistent LDS-DMA flavour (64 < nt <= 136, >= 4096 tiles;
+                                      # there also nt = 128)
+                                      (48, 40, 49), (64, 64, 97), (33, 31, 257), (40, 24, 300), (512, 512, 72), (514, 520, 129),
+                                      (1024, 512, 128), (513, 511, 66)])
 def test_oper_poisson(ny, nx, nt):
     Dsc = 0.37
     rhs = np.asfortranarray(rng.standard_normal((ny, nx, nt)))
@@ -176,6 +181,21 @@ def test_oper_poisson(ny, nx, nt):
         ref = oper_poisson(kernel, rhs).ravel(order="F")
     got = D.oper_poisson3dim(Dsc ** 2, rhs)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ny,nx,nt", [(512, 512, 72), (1024, 512, 128), (514, 520, 129)])
+def test_tridiagonal_t_solve_flavours_agree(ny, nx, nt, monkeypatch):
+    """The t axis of the Poisson solve as tridiagonal systems: the persistent LDS-DMA kernel (k_tsolve_pipe), the
+    one-tile-per-workgroup kernel (DOTSOCP_TS_PIPE=0) -- the same arithmetic on the same registers, bit for bit -- and the
+    transform passes along t (DOTSOCP_TSOLVE=dct), another algorithm for the same linear systems: rounding."""
+    rhs = np.asfortranarray(np.random.default_rng(5).standard_normal((ny, nx, nt)))
+    a = D.oper_poisson3dim(0.37 ** 2, rhs)
+    monkeypatch.setenv("DOTSOCP_TS_PIPE", "0")
+    b = D.oper_poisson3dim(0.37 ** 2, rhs)
+    monkeypatch.setenv("DOTSOCP_TSOLVE", "dct")
+    c = D.oper_poisson3dim(0.37 ** 2, rhs)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(a, c, rtol=0, atol=2e-12 * np.abs(c).max())
 
 
 def test_pipelined_dct_kernels_against_the_workgroup_wide_ones():
