@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-BUILD_ROUND = 3         # profiles/cone_proj_traffic.json is only quoted when it was measured on this round's build
+BUILD_ROUND = 4         # profiles/cone_proj_traffic.json is only quoted when it was measured on this round's build
 
 
 def parse_args():
