@@ -194,7 +194,10 @@ def test_tridiagonal_t_solve_flavours_agree(ny, nx, nt, monkeypatch):
     b = D.oper_poisson3dim(0.37 ** 2, rhs)
     monkeypatch.setenv("DOTSOCP_TSOLVE", "dct")
     c = D.oper_poisson3dim(0.37 ** 2, rhs)
-    np.testing.assert_array_equal(a, b)
+    if nt & (nt - 1):
+        np.testing.assert_array_equal(a, b)
+    else:       # a power of two without the pipelined flavour goes back to the transform pass (tsolve_tri_preferred)
+        np.testing.assert_array_equal(b, c)
     np.testing.assert_allclose(a, c, rtol=0, atol=2e-12 * np.abs(c).max())
 
 
