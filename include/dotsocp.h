@@ -167,18 +167,20 @@ typedef struct {
 
 /* `device` = HIP device ordinal.  `nslabs` >= 1 splits the time axis into that many slabs that live in this one
  * process ON THAT ONE DEVICE (the multi-GPU algorithm -- halo exchange and the t-axis coupling of the Poisson
- * solve -- with every slab on its own pair of streams and device-to-device copies as messages): a rehearsal /
- * diagnostic mode.  Multi-GPU runs use either
+ * solve -- with the slabs sharing the device's pair of streams, one after the other, and pull launches as messages): a
+ * rehearsal / diagnostic mode.  Multi-GPU runs use either
  *   - dotsocp_create_multi(): ONE process, slab r on device (first_device + r) mod #visible devices, neighbour layers
  *     and the interface values of the t-solve travel as peer copies (hipMemcpyPeerAsync over xGMI), per-device KKT
  *     partial sums are added up on the host.  This is what a single MATLAB process (solver_dotsocp2d.m:208 calls
  *     the loop synchronously from the interpreter thread) uses: opts.ngpu of the MEX gateway.  With fewer devices
- *     than slabs, slabs share devices (one device: same as dotsocp_create(prob, device, ngpu)).  upload / download /
+ *     than slabs, slabs share devices (every slab keeps its OWN pair of streams, also on one device: that is what the
+ *     tests of the cross-slab ordering run).  upload / download /
  *     recover_outputs take and return the GLOBAL fields, exactly as with one slab.  STATUS: every loop is verified with
  *     2 .. 8 slabs on concurrent streams of ONE device (the build's boxes have one GPU); slabs on DIFFERENT devices
  *     (hipDeviceEnablePeerAccess, hipMemcpyPeerAsync, cross-device stream waits) have never run on hardware.  Between
  *     different devices messages travel as event-ordered peer copies by default; the launches that pull them through
- *     peer pointers are opt-in there (DOTSOCP_MSG_BATCH=1, DOTSOCP_TRI_GATHER=1); or
+ *     peer pointers are opt-in there (DOTSOCP_MSG_BATCH=1, DOTSOCP_TRI_GATHER=1), and so is one issuing host thread per
+ *     slab (DOTSOCP_HOST_THREADS=1); or
  *   - one process per GPU: dotsocp_create(prob, device, 1) + dotsocp_attach_rccl() (bench.py, torch.distributed). */
 dotsocp_ctx *dotsocp_create(const dotsocp_problem *prob, int device, int nslabs);
 dotsocp_ctx *dotsocp_create_multi(const dotsocp_problem *prob, int first_device, int ngpu);
