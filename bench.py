@@ -283,10 +283,10 @@ def main():
         if args.workload != "dot2d":
             raise SystemExit("multi-GPU bench runs the dot2d workload")
 
-    # --rank-share: a rank's iteration is ~1.7 ms and issues ~40 launches; the ~20 per-phase HIP events per iteration that feed
+    # --rank-share and N > 1: a rank's iteration is ~1.7 ms and issues ~40 launches; the ~20 per-phase HIP events per iteration that feed
     # `kernel_ms` cost it 4-5 % (they cost the 11 ms full-grid iteration nothing measurable).  Its timed pass therefore runs
     # WITHOUT them and a second, untimed pass of the same length WITH them fills `kernel_ms` / `roofline`
-    two_pass = bool(share) and not os.environ.get("DOTSOCP_BENCH_NOPROF")
+    two_pass = (bool(share) or world > 1) and not os.environ.get("DOTSOCP_BENCH_NOPROF")
     opts = dict(tau=1.0 if args.method == "ALG2" else 1.9, sigma=1.0, tol=0.0,
                 maxit=args.warmup + args.steps * (2 if two_pass else 1), scaling=True, ifCheckStepByStep=False, time_limit=1e9)
     full_ms = None
@@ -461,6 +461,9 @@ def main():
                      "kernels": kernels},
         "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
     }
+    if two_pass and not share:
+        out["config"]["timed_pass"] = ("without per-phase HIP events (they cost a rank's 1.7 ms iteration 4-5 %); kernel_ms / roofline "
+                                       "come from a second, untimed pass of the same length with them")
     if share:
         out["rank_share"] = {"n": share, "slab": share // 2, "time_nodes": int(ntl),
                              "kernel_ms_sum": round(sum(v[0] * v[1] for v in times.values()) / max(args.steps, 1), 4),

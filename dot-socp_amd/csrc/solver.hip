@@ -521,19 +521,21 @@ int Solver::attach_rccl(const unsigned char *id, int rk, int wd) {
     if (wd > 1) {
         // handshake: the communicator spans `wd` ranks and the neighbours are the ranks this slab expects (also opens
         // the neighbour connections before the first timed iteration)
+        // (on the stream that carries every later message of this communicator: RCCL sees ONE stream)
+        const hipStream_t cs = comm_z ? stream_z : stream;
         double h[4] = {1.0, (double)rk, 0.0, -1.0};
         double *d = nullptr;
         DS_CHECK(dmalloc(&d, 4));
-        DS_HIP(ds_memcpy_async(d, h, sizeof h, hipMemcpyHostToDevice, stream));
-        DS_NCCL(api.AllReduce(d, d + 2, 1, ncclDouble, ncclSum, comm, stream));
+        DS_HIP(ds_memcpy_async(d, h, sizeof h, hipMemcpyHostToDevice, cs));
+        DS_NCCL(api.AllReduce(d, d + 2, 1, ncclDouble, ncclSum, comm, cs));
         DS_NCCL(api.GroupStart());
         ++open_groups;
-        if (rk + 1 < wd) DS_NCCL_G(api.Send(d + 1, 1, ncclDouble, rk + 1, comm, stream));
-        if (rk > 0) DS_NCCL_G(api.Recv(d + 3, 1, ncclDouble, rk - 1, comm, stream));
+        if (rk + 1 < wd) DS_NCCL_G(api.Send(d + 1, 1, ncclDouble, rk + 1, comm, cs));
+        if (rk > 0) DS_NCCL_G(api.Recv(d + 3, 1, ncclDouble, rk - 1, comm, cs));
         --open_groups;
         DS_NCCL(api.GroupEnd());
-        DS_HIP(ds_memcpy_async(h, d, sizeof h, hipMemcpyDeviceToHost, stream));
-        DS_HIP(ds_stream_synchronize(stream));
+        DS_HIP(ds_memcpy_async(h, d, sizeof h, hipMemcpyDeviceToHost, cs));
+        DS_HIP(ds_stream_synchronize(cs));
         dfree(d);
         if (h[2] != (double)wd || (rk > 0 && h[3] != (double)(rk - 1))) {
             set_error("RCCL handshake failed: %g ranks answered (expected %d), left neighbour says %g (expected %d)", h[2], wd,
