@@ -186,3 +186,28 @@ def test_bench_self_launch_rehearsal(world):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == world and rec["steps"] == 12 and rec["config"]["grid"] == [64, 48, 16]
     assert np.isfinite(rec["value"]) and rec["value"] > 0
+
+
+def test_bench_rank_share_line():
+    """`bench.py --rank-share N` (one rank's slab of the N-way split through the code path of a real rank, its messages as
+    local copies in tools/libloopback_rccl.so) on a small grid: the line carries the full grid's time of the SAME process and
+    the ratio of the two (round-3 verdict: same-run pairs only), and says that its timed pass ran without per-phase events."""
+    import json
+    lb = os.path.join(ROOT, "tools", "libloopback_rccl.so")
+    if not os.path.exists(lb):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "--offload-arch=gfx950", "-o", lb,
+                               os.path.join(ROOT, "tools", "loopback_rccl.cpp")])
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DOTSOCP_RCCL_LIB"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rank-share", "4", "--steps", "12", "--warmup", "3",
+           "--no-cpu-baseline", "--grid", "64", "48", "64"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    rs = rec["rank_share"]
+    assert rs["n"] == 4 and rs["time_nodes"] == 16
+    assert rs["full_grid_ms_per_step"] > 0 and abs(rs["ceiling"] - rs["full_grid_ms_per_step"] / rec["ms_per_step"]) < 1e-9
+    assert rec["config"]["per_phase_hip_events_in_timed_region"] is False and "without per-phase" in rs["timed_pass"]
+    assert rec["kernel_ms"]["poisson"] > 0 and rec["kernel_ms"]["comm"] > 0          # the second, instrumented pass
+    assert rec["config"]["box_copy_gbs"] is None or rec["config"]["box_copy_gbs"] > 100
