@@ -220,7 +220,7 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
                        int rank, i64 l0, i64 nl, const i64 *slab_n, const double *recv, double *back, double *zero_work,
                        hipStream_t st, const double *own_recv = nullptr, double *own_back = nullptr);
 int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
-                     const double *back, double *x, double *qinv, hipStream_t st);
+                     const double *back, double *x, hipStream_t st);
 // the SINGLE slab's t-axis solve by the same elimination, in place on x = [g.plane][nt] (no transform along t; any nt <= 512)
 bool tsolve_tri_supported(i64 nt);
 bool tsolve_tri_preferred(i64 nt, bool pow2, i64 plane);      // faster than the transform pass(es) along t?

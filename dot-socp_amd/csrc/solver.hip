@@ -962,7 +962,7 @@ int Solver::poisson_t_tridiag(const PhiHooks *hooks) {
     }
     if (async) DS_CHECK(comm_wait(&Slab::ev_halo));
     if (hooks && hooks->behind) DS_CHECK(hooks->behind());
-    FOR_SLABS(s) DS_CHECK(launch_tri_final(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.tri_brecv, s.w0, s.w1, s.st));
+    FOR_SLABS(s) DS_CHECK(launch_tri_final(s.g, nt, kscale, s.res->cy, s.res->cx, pc, s.tri_brecv, s.w0, s.st));
     return 0;
 }
 

@@ -1,4 +1,5 @@
-// Time-slab Poisson solve WITHOUT the slab <-> pencil transposes (option B).
+// The t axis of the Poisson solve as tridiagonal systems: across time slabs WITHOUT the slab <-> pencil transposes
+// (option B), and -- the same elimination inside one workgroup -- on the single slab (k_tsolve_*).
 //
 // After the y and x transforms every (ky, kx) mode is an independent system along t,
 //     D^2 ((CY[ky] + CX[kx]) I + T) phi = r ,   T = (nt-1)^2 tridiag(-1, [1, 2, ..., 2, 1], -1)
@@ -407,7 +408,7 @@ int launch_tri_reduced(const Grid &g, i64 nt, double kscale, const double *cy, c
 }
 
 int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, const double *cx, const PencilCuts &pc,
-                     const double *back, double *x, double *qinv, hipStream_t st) {
+                     const double *back, double *x, hipStream_t st) {
     const TriGeom t = make_geom(g, nt, kscale, cy, cx, pc);
     const dim3 grid((unsigned)((g.plane + 255) / 256));
     const int rw = tri_reg_width(g.ntl);
@@ -415,7 +416,6 @@ int launch_tri_final(const Grid &g, i64 nt, double kscale, const double *cy, con
     else if (rw == 32) DS_KLAUNCH(k_tri_final_reg<32>, grid, dim3(256), 0, st, t, back, x);
     else if (rw == 64) DS_KLAUNCH(k_tri_final_reg<64>, grid, dim3(256), 0, st, t, back, x);
     else DS_KLAUNCH(k_tri_final, grid, dim3(256), 0, st, t, back, x);
-    (void)qinv;
     DS_HIP(hipGetLastError());
     return 0;
 }
