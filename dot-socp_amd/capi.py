@@ -73,6 +73,7 @@ SYMBOLS = {
     "dotsocp_slab_range": (ctypes.c_int, [i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
     "dotsocp_field_len": (i64, [ctypes.POINTER(Problem), ctypes.c_int]),
     "dotsocp_upload": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "dotsocp_upload_layers": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
     "dotsocp_download": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "dotsocp_begin": (ctypes.c_int, [vp, ctypes.POINTER(Opts)]),
     "dotsocp_begin_method": (ctypes.c_int, [vp, ctypes.POINTER(Opts), ctypes.c_int, ctypes.POINTER(AccOpts)]),

@@ -317,6 +317,10 @@ dotsocp_i64 dotsocp_field_len(const dotsocp_problem *p, int field) {
 }
 
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host) { CTX_OR_FAIL(); return ctx->s.upload(field, host); }
+int dotsocp_upload_layers(dotsocp_ctx *ctx, int field, const double *host, dotsocp_i64 t0, dotsocp_i64 n) {
+    CTX_OR_FAIL();
+    return ctx->s.upload_layers(field, host, t0, n);
+}
 int dotsocp_download(dotsocp_ctx *ctx, int field, double *host) { CTX_OR_FAIL(); return ctx->s.download(field, host); }
 int dotsocp_begin(dotsocp_ctx *ctx, const dotsocp_opts *opts) { CTX_OR_FAIL(); return ctx->s.begin(opts); }
 int dotsocp_begin_method(dotsocp_ctx *ctx, const dotsocp_opts *opts, int method, const dotsocp_acc_opts *acc) {

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "hostmem.h"
 #include "kernels.h"
 
 namespace dotsocp {
@@ -223,6 +224,7 @@ struct Solver {
     int init(const dotsocp_problem *p, int device, int nslabs, bool multi_dev = false);
     int attach_rccl(const unsigned char *id, int rank, int world);
     int upload(int field, const double *host);
+    int upload_layers(int field, const double *host, i64 t0, i64 n);
     int download(int field, double *host);
     int begin(const dotsocp_opts *o);
     int begin_method(const dotsocp_opts *o, int method, const dotsocp_acc_opts *acc);

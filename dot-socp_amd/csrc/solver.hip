@@ -1053,6 +1053,32 @@ int Solver::upload(int field, const double *host) {
     return copy_field(*this, field, const_cast<double *>(host), true);
 }
 
+// time layers [t0, t0 + n) of a node field (phi, c) from a host buffer that holds only those layers; the other layers
+// keep what they have (zeros after create).  model.c of initialize.m:42-50 is zero except for its first and last layer:
+// a driver uploads those two instead of a vector as long as the grid (1 GB at 1025 x 1025 x 129).
+int Solver::upload_layers(int field, const double *host, i64 t0, i64 n) {
+    DS_ARG(host != nullptr, "host pointer is NULL");
+    DS_ARG(field == DOTSOCP_F_PHI || field == DOTSOCP_F_C, "layer uploads serve the node fields (phi, c)");
+    const i64 ntn = remote() ? slabs[0].g.ntl : nt;
+    DS_ARG(t0 >= 0 && n >= 0 && t0 + n <= ntn, "layer range outside the field");
+    if (begun) { set_error("upload() after begin()"); return DOTSOCP_ESTATE; }
+    cur_dev = -1;
+    DS_CHECK(use_dev(device));
+    DS_CHECK(ensure_alloc());
+    const i64 hplane = ny * nx;
+    for (auto &s : slabs) {
+        DS_CHECK(use(s));
+        const Grid &g = s.g;
+        const i64 base = remote() ? 0 : g.t0;
+        const i64 lo = std::max(t0, base), hi = std::min(t0 + n, base + g.ntl);
+        if (lo >= hi) continue;
+        double *dev = (field == DOTSOCP_F_PHI ? s.phi : s.c) + g.plane * (lo - base);
+        DS_CHECK(copy_rows(dev, const_cast<double *>(host) + hplane * (lo - t0), ny, g.py, nx * (hi - lo), true, s.st));
+    }
+    DS_CHECK(sync_all());
+    return 0;
+}
+
 int Solver::download(int field, double *host) {
     DS_ARG(host != nullptr, "host pointer is NULL");
     DS_ARG(field_len(field) >= 0, "unknown field");
@@ -1065,12 +1091,10 @@ int Solver::download(int field, double *host) {
         DS_CHECK(flush_beta());
     }
     if (field == DOTSOCP_F_ALPHA) DS_CHECK(flush_alpha());
+    host_first_touch(host, sizeof(double) * (size_t)field_len(field));
     DS_CHECK(copy_field(*this, field, host, false));
     // after finish(): var.alpha = sigma * alpha, var.beta = sigma * beta  (solver_socp_inPALM.m:335-336)
-    if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) {
-        const i64 n = field_len(field);
-        for (i64 i = 0; i < n; ++i) host[i] = sigma * host[i];
-    }
+    if (finished && (field == DOTSOCP_F_ALPHA || field == DOTSOCP_F_BETA)) host_scale(host, field_len(field), sigma);
     return 0;
 }
 

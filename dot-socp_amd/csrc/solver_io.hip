@@ -29,6 +29,11 @@ int Solver::recover_outputs(const double *rho0, const double *rho1, double *rho,
     double *outs[6] = {rho, Ex, Ey, q0, bx, by};
     for (int which = 0; which < 6; ++which) {
         if (!outs[which]) continue;
+        {   // the host array of this output (this process's layers of it): make its pages exist before the copies
+            i64 layers = 0;
+            for (auto &s : slabs) layers += (which >= 3) ? s.g.ncl : s.g.ntl;
+            host_first_touch(outs[which], sizeof(double) * (size_t)(hplane * layers));
+        }
         FOR_SLABS(s) {
             const Grid &g = s.g;
             double *d_r0 = s.w1, *d_r1 = s.w1 + plane;     // w1 holds at least two layers (nt >= 2 per slab)

@@ -79,9 +79,17 @@ class InPALMContext:
             # a field left as None keeps the device default (zeros), e.g. z, beta, q, alpha of a cold start
             state = () if warm_from is not None else ((capi.F_PHI, var.phi), (capi.F_Q, var.q), (capi.F_ALPHA, var.alpha),
                                                       (capi.F_Z, var.z), (capi.F_BETA, var.beta))
-            for f, a in state + ((capi.F_C, model.c),):
+            for f, a in state:
                 if a is not None:
                     self.upload(f, a)
+            ends = getattr(model, "_c_ends", None)
+            if ends is not None and model.c.size > 2 * ends and rccl is None:
+                # initialize(lazy_zeros=True): c is zero between its first and last layer, as the device array is
+                nlay = model.c.size // ends
+                for t, part in ((0, model.c[:ends]), (nlay - 1, model.c[model.c.size - ends:])):
+                    capi.check(L.dotsocp_upload_layers(self._ctx, capi.F_C, capi.fptr(np.ascontiguousarray(part)), t, 1))
+            else:
+                self.upload(capi.F_C, model.c)
             if weighted:
                 self.upload(capi.F_WEIGHT, model.weight)
             if warm_from is not None:
@@ -342,9 +350,8 @@ def _solve_levels(rho0, rho1, nt, levelN, opts, method, dim, weighted, device, b
                 wf = ws[lv + 1] if weighted else None
                 if on_device:
                     E2 = var.E2
-                    var, model = initialize(rho0s[lv + 1], rho1s[lv + 1], nts[lv + 1], lazy_zeros=True)
-                    var.phi, var.E2 = None, E2          # state comes from the coarse level on the device
-                    model.n_global = model.c.size
+                    var, model = initialize(rho0s[lv + 1], rho1s[lv + 1], nts[lv + 1], lazy_zeros=True, phi=False)
+                    var.E2 = E2                         # the state comes from the coarse level on the device
                     if weighted:
                         model.weight = wf
                     prev = ctx

@@ -207,6 +207,11 @@ dotsocp_i64 dotsocp_field_len(const dotsocp_problem *prob, int field);
 
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host);
 int dotsocp_download(dotsocp_ctx *ctx, int field, double *host);
+/* Extension for drivers: time layers [t0, t0 + n) of a NODE field (DOTSOCP_F_PHI, DOTSOCP_F_C) from a host buffer that
+ * holds just those n layers of ny*nx doubles (with an RCCL communicator: layers of this process's slab); the other layers
+ * keep their contents (zeros after create).  model.c of socp/dot2d/utils/initialize.m:42-50 is zero except for its first
+ * and last layer, so a driver hands over two layers instead of a grid-sized vector. */
+int dotsocp_upload_layers(dotsocp_ctx *ctx, int field, const double *host, dotsocp_i64 t0, dotsocp_i64 n);
 
 /* solver_socp_inPALM.m:11-135 (setup), :136-325 (loop; `n_iters` < 0 = until maxit /
  * stop), :329-357 (outputs).  run() may be called repeatedly; the trajectory is identical

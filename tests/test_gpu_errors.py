@@ -75,6 +75,72 @@ def test_call_sequence_is_enforced():
     assert _code(L.dotsocp_run(None, 1, None)) == -1                                  # NULL context
 
 
+@pytest.mark.parametrize("ny,nx,nt,nslabs", [(16, 12, 8, 1), (33, 17, 9, 1), (16, 12, 9, 3), (1, 24, 6, 1)])
+def test_upload_layers_equals_the_full_upload(ny, nx, nt, nslabs):
+    """dotsocp_upload_layers (driver extension: c's two non-zero layers instead of the whole vector): any layer range of
+    phi / c lands where the full upload puts it -- pitched rows, time slabs, the 1-D engine layout (ny x 1) --, the other
+    layers keep their contents; bad fields, ranges and call order are refused."""
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    one_d = ny == 1
+    p = _problem(ny=ny, nx=nx, nt=nt, dim=1 if one_d else 2)
+    plane = nx if one_d else ny * nx
+    full = rng.standard_normal(plane * nt)
+    for field in (capi.F_C, capi.F_PHI):
+        a = L.dotsocp_create(ctypes.byref(p), 0, nslabs)
+        b = L.dotsocp_create(ctypes.byref(p), 0, nslabs)
+        assert a and b
+        try:
+            capi.check(L.dotsocp_upload(a, field, capi.fptr(full)))
+            want = full.copy()
+            got0 = np.empty_like(full)
+            capi.check(L.dotsocp_download(b, field, capi.fptr(got0)))
+            assert not got0.any()                                                       # zeros after create
+            expect = np.zeros_like(full)
+            for t0, n in ((0, 1), (nt - 1, 1), (2, 3), (1, 0)):
+                part = np.ascontiguousarray(full[plane * t0:plane * (t0 + n)]) if n else np.zeros(1)
+                capi.check(L.dotsocp_upload_layers(b, field, capi.fptr(part), t0, n))
+                expect[plane * t0:plane * (t0 + n)] = full[plane * t0:plane * (t0 + n)]
+            got = np.empty_like(full)
+            capi.check(L.dotsocp_download(b, field, capi.fptr(got)))
+            assert np.array_equal(got, expect)
+            capi.check(L.dotsocp_upload_layers(b, field, capi.fptr(full), 0, nt))       # the whole range
+            capi.check(L.dotsocp_download(b, field, capi.fptr(got)))
+            capi.check(L.dotsocp_download(a, field, capi.fptr(want)))
+            assert np.array_equal(got, want) and np.array_equal(got, full)
+            assert _code(L.dotsocp_upload_layers(b, capi.F_Q, capi.fptr(full), 0, 1)) == -1       # not a node field
+            assert _code(L.dotsocp_upload_layers(b, field, capi.fptr(full), nt - 1, 2)) == -1     # past the end
+            assert _code(L.dotsocp_upload_layers(b, field, capi.fptr(full), -1, 1)) == -1
+            assert _code(L.dotsocp_upload_layers(b, field, None, 0, 1)) == -1
+            o = _opts()
+            capi.check(L.dotsocp_begin(b, ctypes.byref(o)))
+            assert _code(L.dotsocp_upload_layers(b, field, capi.fptr(full), 0, 1)) == -4          # after begin
+        finally:
+            L.dotsocp_destroy(a)
+            L.dotsocp_destroy(b)
+
+
+def test_driver_start_with_lazy_fields_equals_the_eager_one():
+    """initialize(lazy_zeros=True, phi=...) + InitialScaling + InPALMContext (c handed over as its two end layers, norms
+    from those layers, z / beta / q / alpha left to the device default) runs the trajectory of the eager set-up."""
+    from oracle import driver as OD
+    from oracle.examples import get_example_2d
+    rho0, rho1 = get_example_2d("example1", 24, 20)
+    o = OD.default_opts(dict(tol=0.0, maxit=12), "inPALM")
+    res = []
+    for lazy in (False, True):
+        var, model = D.initialize(rho0, rho1, 9, lazy_zeros=lazy)
+        D.InitialScaling(var, model, True, None, dim=2)
+        ctx = D.InPALMContext(var, o, model)
+        assert ctx.run(-1) == 12
+        hist, sigma = ctx.finish(download=False)
+        res.append((ctx.download(capi.F_PHI, var.phi), ctx.download(capi.F_C, model.c), hist["kkt"].copy(), sigma,
+                    var.cScale, model.normc, model.c.copy()))
+        ctx.close()
+    for x, y in zip(res[0], res[1]):     # ||c|| is summed over two layers instead of the whole vector: the last bit may differ
+        np.testing.assert_allclose(np.asarray(y), np.asarray(x), rtol=1e-11, atol=1e-13 * np.abs(np.asarray(x)).max())
+
+
 def test_variant_restrictions():
     L = capi.lib()
     o = _opts()

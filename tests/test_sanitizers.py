@@ -56,3 +56,21 @@ def test_slab_thread_layer_is_clean_under_tsan():
     run = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "0 failed" in run.stdout and "ThreadSanitizer" not in run.stderr
+
+
+def test_host_side_helpers_of_the_download_path_under_tsan_and_asan():
+    """dot-socp_amd/csrc/hostmem.hip (first touch of download targets and the sigma scaling of alpha / beta on several host
+    threads) is plain C++: built with g++ under ThreadSanitizer and under AddressSanitizer + UBSan, driven by
+    tests/san/hostmem_check.cpp -- contents untouched at every alignment, scaling equal to the serial loop bit for bit."""
+    os.makedirs(OUT, exist_ok=True)
+    csrc = os.path.join(ROOT, "dot-socp_amd", "csrc")
+    for name, flags in (("tsan", ["-fsanitize=thread"]), ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])):
+        exe = os.path.join(OUT, "hostmem_" + name)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread"] + flags + ["-x", "c++", "-I" + csrc,
+                               os.path.join(csrc, "hostmem.hip"), os.path.join(ROOT, "tests", "san", "hostmem_check.cpp"), "-o", exe])
+        for threads in ("1", "5"):
+            run = subprocess.run([exe], env=dict(os.environ, DOTSOCP_HOST_COPY_THREADS=threads, TSAN_OPTIONS="halt_on_error=1",
+                                                 ASAN_OPTIONS="halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1"),
+                                 capture_output=True, text=True, timeout=600)
+            assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+            assert f"threads {threads}, 0 failed" in run.stdout and "Sanitizer" not in run.stderr
