@@ -131,6 +131,62 @@ def test_trajectory_wdot2d(n, nt, K):
     _compare_run(rho0, rho1, nt, dict(tol=0.0), K, weight=weight, tol=1e-8)
 
 
+@pytest.mark.parametrize("case,K,nslabs", [("dot2d", 1, 1), ("dot2d", 3, 1), ("dot1d", 1, 1), ("dot1d", 3, 1), ("wdot2d", 2, 1),
+                                           ("dot2d", 3, 2), ("dot2d", 3, 3), ("dot1d", 3, 2), ("wdot2d", 2, 3)])
+def test_iterations_from_a_random_state(case, K, nslabs, request):
+    """The steps of ONE iteration in isolation from any trajectory: phi, q, alpha and beta are
+    random -- every term of the q-step's right-hand side, of its diagonal, of the multiplier updates and of the KKT sums
+    is generic, none vanishes as in the all-zero start of initialize.m -- and one to three iterations with a KKT check in
+    each are compared with the oracle field by field.  (z comes in as zeros: solver_socp_inPALM.m:199 overwrites it before
+    its first use.)  nslabs > 1: the same on time slabs, whose very first halo exchanges then carry generic layers.
+    beta is zero where the cone row has no edge (the slots mexBFd leaves unwritten at the domain boundary): the reference
+    never makes them non-zero, and compute_kkt_dot_complement reads what the projection of :240 left in those slots of
+    the shared temporary z2 (:242 does not overwrite them) -- stale data the device, which builds z2 in registers, does
+    not reproduce."""
+    if nslabs > 1 and "unfused" in request.node.name:
+        pytest.skip("time slabs run the fused dataflow")
+    rng = np.random.default_rng(11)
+    weight = None
+    if case == "dot1d":
+        rho0, rho1 = get_example_1d("gaussian", 48)
+        nt = 10
+    else:
+        rho0, rho1 = get_example_2d("example1", 20, 28)
+        nt = 9
+        if case == "wdot2d":
+            barrier = gene_barrier_of_circle_pillar()
+            weight = get_weight_by_barrier(20, 28, nt, barrier)
+            rho0, rho1, _ = ensure_barrier_validity(rho0, rho1, barrier)
+    opts = dict(tol=0.0, maxit=K, ifCheckStepByStep=True, sigma=0.7)
+    ovar, omodel, oo = OD.make_level(rho0, rho1, nt, opts, "inPALM", weight)
+    gvar, gmodel, go = _gpu_level(rho0, rho1, nt, opts, "inPALM", weight)
+    start = {"phi": rng.standard_normal(ovar.phi.shape), "q": 0.3 * rng.standard_normal(ovar.q.shape),
+             "alpha": 0.5 * rng.standard_normal(ovar.alpha.shape),
+             "beta": np.asfortranarray(0.4 * rng.standard_normal(ovar.beta.shape))}
+    from oracle import mexops
+    probe = np.full(ovar.beta.shape, np.nan, order="F")
+    if case == "dot1d":
+        mexops.mexBFd1d(probe, start["q"], nt, rho0.size)
+    else:
+        mexops.mexBFd(probe, start["q"], nt, rho0.shape[1], rho0.shape[0])
+    assert 0 < np.isnan(probe).sum() < probe.size // 4
+    start["beta"][np.isnan(probe)] = 0.0
+    for v in (ovar, gvar):
+        for f, a in start.items():
+            setattr(v, f, a.copy(order="F"))
+    st = InPALMState(ovar, oo, omodel, weighted=weight is not None)
+    st.run()
+    o_hist, o_sigma = st.finish()
+    solve = D.solver_wsocp_inPALM if weight is not None else D.solver_socp_inPALM
+    g_hist, g_sigma = solve(gvar, go, gmodel, nslabs=nslabs)
+    assert g_hist["len"] == o_hist["len"] == K
+    assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
+    np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-8, atol=1e-12)
+    errs = {f: _relerr(getattr(gvar, f), getattr(ovar, f)) for f in FIELDS}
+    assert max(errs.values()) <= 1e-11, errs
+    assert _relerr(gvar.q, start["q"]) > 1e-2 and _relerr(gvar.beta, start["beta"]) > 1e-2     # the state did move
+
+
 def test_free_running_solve_dot2d():
     """Full solve to tolerance through the driver: same stop iteration as the oracle, KKT < tol,
     per-layer mass conservation (solver_dotsocp2d.m:283-287)."""
