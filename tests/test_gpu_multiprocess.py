@@ -24,7 +24,41 @@ def _build_fake():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-Wno-unused-result", "-o", FAKE_SO, src])
 
 
-def _worker(rank, world, uid_hex, q, NT, method="inPALM"):
+def _random_state(NT):
+    """a generic global state in the reference layout (seeded: every process builds the same one); z and beta are zero in
+    the slots of cone rows without an edge (tests/test_gpu_random_state.py says why)"""
+    from oracle import mexops
+    rng = np.random.default_rng(31)
+    nz = NY * NX * (NT - 1)
+    nq = nz + NY * (NX - 1) * NT + (NY - 1) * NX * NT
+    st = {"phi": rng.standard_normal(NY * NX * NT), "q": 0.3 * rng.standard_normal(nq), "alpha": 0.5 * rng.standard_normal(nq),
+          "z": np.asfortranarray(0.6 * rng.standard_normal((nz, 10))), "beta": np.asfortranarray(0.4 * rng.standard_normal((nz, 10)))}
+    probe = np.full((nz, 10), np.nan, order="F")
+    mexops.mexBFd(probe, st["q"], NT, NX, NY)
+    st["z"][np.isnan(probe)] = 0.0
+    st["beta"][np.isnan(probe)] = 0.0
+    return st
+
+
+def _slab_of(st, NT, t0, t1):
+    """the layers [t0, t1) of a global state: what a rank of the one-process-per-GPU mode holds and uploads"""
+    ntl = t1 - t0
+    ncl = ntl if t1 < NT else ntl - 1
+    nz = NY * NX * (NT - 1)
+    nbx = NY * (NX - 1) * NT
+    out = {"phi": st["phi"].reshape((NY, NX, NT), order="F")[:, :, t0:t1].ravel(order="F")}
+    for f in ("q", "alpha"):
+        v = st[f]
+        c0 = v[:nz].reshape((NY, NX, NT - 1), order="F")[:, :, t0:t0 + ncl]
+        bx = v[nz:nz + nbx].reshape((NY, NX - 1, NT), order="F")[:, :, t0:t1]
+        by = v[nz + nbx:].reshape((NY - 1, NX, NT), order="F")[:, :, t0:t1]
+        out[f] = np.concatenate([c0.ravel(order="F"), bx.ravel(order="F"), by.ravel(order="F")])
+    for f in ("z", "beta"):
+        out[f] = np.asfortranarray(st[f].reshape((NY, NX, NT - 1, 10), order="F")[:, :, t0:t0 + ncl].reshape((NY * NX * ncl, 10), order="F"))
+    return out
+
+
+def _worker(rank, world, uid_hex, q, NT, method="inPALM", start="zeros"):
     os.environ["DOTSOCP_RCCL_LIB"] = FAKE_SO
     sys.path.insert(0, ROOT)
     try:
@@ -36,6 +70,9 @@ def _worker(rank, world, uid_hex, q, NT, method="inPALM"):
         var, model = D.initialize_slab(rho0, rho1, NT, t0, t1)
         o = OD.default_opts(dict(tol=0.0, maxit=K), method, False)
         D.InitialScaling(var, model, True, None, dim=2)
+        if start == "random":
+            for f, a in _slab_of(_random_state(NT), NT, t0, t1).items():
+                setattr(var, f, a)
         ctx = D.InPALMContext(var, o, model, rccl=(bytes.fromhex(uid_hex), rank, world), method=method)
         ctx.run(-1)
         hist, sigma = ctx.finish(download=False)
@@ -81,7 +118,15 @@ def test_accadmm_one_process_per_slab(world, NT, monkeypatch):
     _one_process_per_slab(world, "tridiag", NT, "acc-ADMM", monkeypatch)
 
 
-def _one_process_per_slab(world, tsolve, NT, method, monkeypatch):
+@pytest.mark.parametrize("world,NT,method", [(2, 16, "inPALM"), (3, 48, "inPALM"), (4, 64, "inPALM"), (3, 48, "PALM"), (2, 32, "acc-ADMM")])
+def test_one_process_per_slab_from_a_random_state(world, NT, method, monkeypatch):
+    """Every rank uploads ITS layers of one generic global state (phi, q, z, alpha, beta all non-zero): the slab-local
+    field layout of upload(), the first halo / u0 / tail exchanges with generic layers, and the loop against the
+    single-process run from the same state."""
+    _one_process_per_slab(world, "tridiag", NT, method, monkeypatch, start="random")
+
+
+def _one_process_per_slab(world, tsolve, NT, method, monkeypatch, start="zeros"):
     monkeypatch.setenv("DOTSOCP_TSOLVE", tsolve)        # inherited by the rank processes
     import multiprocessing as mp
     _build_fake()
@@ -94,6 +139,9 @@ def _one_process_per_slab(world, tsolve, NT, method, monkeypatch):
     var, model = D.initialize(rho0, rho1, NT)
     o = OD.default_opts(dict(tol=0.0, maxit=K), method, False)
     D.InitialScaling(var, model, True, None, dim=2)
+    if start == "random":
+        for f, a in _random_state(NT).items():
+            setattr(var, f, a)
     solve1 = {"PALM": D.solver_socp_PALM, "acc-ADMM": D.solver_socp_accADMM}.get(method, D.solver_socp_inPALM)
     hist1, sigma1 = solve1(var, o, model)
     phi1 = var.phi.reshape((NY, NX, NT), order="F")
@@ -107,7 +155,7 @@ def _one_process_per_slab(world, tsolve, NT, method, monkeypatch):
     uid = D.capi.rccl_unique_id()
     ctx = mp.get_context("spawn")
     qu = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu, NT, method)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, uid.hex(), qu, NT, method, start)) for r in range(world)]
     for p in procs:
         p.start()
     results = [qu.get(timeout=300) for _ in procs]

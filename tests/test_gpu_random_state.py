@@ -21,10 +21,15 @@ def _relerr(a, b):
     return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
 
 
-@pytest.mark.parametrize("nslabs", [1, 2, 3])
+@pytest.mark.parametrize("split", ["nslabs=1", "nslabs=2", "nslabs=3", "ngpu=2", "ngpu=3"])
 @pytest.mark.parametrize("K", [1, 3])
-@pytest.mark.parametrize("method", ["PALM", "acc-ADMM"])
-def test_iterations_from_a_random_state(method, K, nslabs):
+@pytest.mark.parametrize("method", ["PALM", "acc-ADMM", "inPALM"])
+def test_iterations_from_a_random_state(method, K, split):
+    """split: nslabs = time slabs on one device sharing a stream pair; ngpu = dotsocp_create_multi (a stream pair per slab,
+    event-ordered messages; the devices wrap around on a one-GPU box)"""
+    kind, n = split.split("=")
+    if method == "inPALM" and kind == "nslabs":
+        pytest.skip("covered by tests/test_gpu_solver.py::test_iterations_from_a_random_state")
     rng = np.random.default_rng(23)
     ny, nx, nt = 20, 28, 9
     rho0, rho1 = get_example_2d("example1", ny, nx)
@@ -48,8 +53,12 @@ def test_iterations_from_a_random_state(method, K, nslabs):
     st = OD.make_state(ovar, oo, omodel, method)
     st.run()
     o_hist, o_sigma = st.finish()
-    solve = D.solver_socp_PALM if method == "PALM" else D.solver_socp_accADMM
-    g_hist, g_sigma = solve(gvar, oo, gmodel, nslabs=nslabs)
+    ctx = D.InPALMContext(gvar, oo, gmodel, method=method, **{kind: int(n)})
+    try:
+        ctx.run(-1)
+        g_hist, g_sigma = ctx.finish()
+    finally:
+        ctx.close()
     assert g_hist["len"] == o_hist["len"] == K
     assert abs(g_sigma - o_sigma) <= 1e-12 * abs(o_sigma)
     np.testing.assert_allclose(g_hist["kkt"], o_hist["kkt"], rtol=1e-8, atol=1e-12)
