@@ -15,6 +15,7 @@ if len(sys.argv) > 3:
     cases = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)]
 for n, nt, L in cases:
     rho0, rho1 = D.get_example_2d("example1", n, n)
+    out = None                                    # the previous case's 1 GB output arrays are freed outside the timed call
     t = time.perf_counter()
     out, timeML, histML, hist = D.solver_dotsocp2d(rho0, rho1, nt, L, dict(tol=1e-4, maxit=3000), "inPALM")
     dt = time.perf_counter() - t

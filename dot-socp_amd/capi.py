@@ -72,6 +72,7 @@ SYMBOLS = {
     "dotsocp_attach_rccl": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int]),
     "dotsocp_slab_range": (ctypes.c_int, [i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
     "dotsocp_field_len": (i64, [ctypes.POINTER(Problem), ctypes.c_int]),
+    "dotsocp_release_cache": (i64, []),
     "dotsocp_upload": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "dotsocp_upload_layers": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
     "dotsocp_download": (ctypes.c_int, [vp, ctypes.c_int, vp]),

@@ -25,14 +25,12 @@ static int require_device() {
     return 0;
 }
 
-// RAII device buffer for the host-pointer operator entry points
+// RAII device buffer for the host-pointer operator entry points (through the device block cache of guard.hip: a MATLAB
+// loop over mexBFd / mexProjSoc gets the same buffers back call after call instead of a malloc / free pair per call)
 struct DevBuf {
     double *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(i64 n) {
-        DS_HIP(hipMalloc((void **)&p, sizeof(double) * (size_t)(n > 0 ? n : 1)));
-        return 0;
-    }
+    ~DevBuf() { dfree(p); }
+    int alloc(i64 n) { return dmalloc(&p, n); }
 };
 
 extern "C" {
@@ -317,6 +315,8 @@ dotsocp_i64 dotsocp_field_len(const dotsocp_problem *p, int field) {
 }
 
 int dotsocp_upload(dotsocp_ctx *ctx, int field, const double *host) { CTX_OR_FAIL(); return ctx->s.upload(field, host); }
+dotsocp_i64 dotsocp_release_cache(void) { return (dotsocp_i64)device_cache_release(); }
+
 int dotsocp_upload_layers(dotsocp_ctx *ctx, int field, const double *host, dotsocp_i64 t0, dotsocp_i64 n) {
     CTX_OR_FAIL();
     return ctx->s.upload_layers(field, host, t0, n);

@@ -70,9 +70,144 @@ bool canary_enabled() {
     return e && atoi(e) != 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device block cache.  hipFree of a context's buffers is cheap, but the NEXT hipMalloc pays for it: measured on the
+// MI355X boxes, creating a 1025 x 1025 x 129 context (54 GB in ~40 buffers) takes 0.67 s in a fresh process and 1.65 s
+// right after a context of that size was destroyed (one hipMalloc call of 1.6 s: the driver hands freed memory out again
+// only once it is wiped), and a context created next to such a release stalls once for 30-90 ms in its first iterations
+// (DESIGN.md section 6).  A caller that solves one problem size again and again -- the usual MATLAB session -- would pay
+// that on every call.  Freed buffers are therefore kept per device and handed out again to requests of (nearly) their
+// size; a reused buffer is zero-filled, as fresh device memory is; the cache holds at most half of the device's memory
+// (DOTSOCP_DEVICE_CACHE_GB), oldest blocks leave first.  DOTSOCP_DEVICE_CACHE=0 switches the cache off,
+// dotsocp_release_cache() returns everything to the driver, an allocation failure does so by itself and retries.
+namespace {
+
+struct Block {
+    void *p;
+    size_t bytes;
+    int dev;
+};
+std::mutex c_mu;
+std::map<void *, Block> c_live;      // handed out: pointer -> block (with the size it was allocated with)
+std::vector<Block> c_free;
+
+bool cache_enabled() {
+    static const bool on = !(getenv("DOTSOCP_DEVICE_CACHE") && atoi(getenv("DOTSOCP_DEVICE_CACHE")) == 0);
+    return on;
+}
+
+}  // namespace
+
+long long device_cache_release() {
+    std::vector<Block> blocks;
+    {
+        std::lock_guard<std::mutex> lk(c_mu);
+        blocks.swap(c_free);
+    }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    long long bytes = 0;
+    for (auto &b : blocks) {
+        (void)hipSetDevice(b.dev);
+        (void)hipFree(b.p);
+        bytes += (long long)b.bytes;
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+    return bytes;
+}
+
+static int cached_malloc(void **p, size_t bytes) {
+    int dev = 0;
+    DS_HIP(hipGetDevice(&dev));
+    Block got{nullptr, 0, dev};
+    {
+        // best fit among the free blocks of this device that are at most an eighth larger than the request
+        std::lock_guard<std::mutex> lk(c_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c_free.size(); ++i) {
+            const Block &b = c_free[i];
+            if (b.dev != dev || b.bytes < bytes || b.bytes > bytes + bytes / 8 + 65536) continue;
+            if (best == (size_t)-1 || b.bytes < c_free[best].bytes) best = i;
+        }
+        if (best != (size_t)-1) {
+            got = c_free[best];
+            c_free.erase(c_free.begin() + (long)best);
+        }
+    }
+    if (got.p) {
+        // like fresh device memory, a reused block reads as zeros (guarded_free made sure nothing is still using it)
+        hipError_t e = hipMemsetAsync(got.p, 0, got.bytes, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) {
+            (void)hipFree(got.p);
+            DS_HIP(e);
+        }
+    } else {
+        hipError_t e = hipMalloc(&got.p, bytes);
+        if (e != hipSuccess) {                       // out of memory with blocks of other sizes in the cache: give them back, retry
+            (void)hipGetLastError();
+            if (device_cache_release() > 0) e = hipMalloc(&got.p, bytes);
+        }
+        DS_HIP(e);
+        got.bytes = bytes;
+    }
+    *p = got.p;
+    std::lock_guard<std::mutex> lk(c_mu);
+    c_live[got.p] = got;
+    return 0;
+}
+
+static void cached_free(void *p) {
+    Block b{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(c_mu);
+        auto it = c_live.find(p);
+        if (it != c_live.end()) { b = it->second; c_live.erase(it); }
+    }
+    if (!b.p) {
+        (void)hipFree(p);
+        return;
+    }
+    // hipFree waits for the device; a block that goes back into the cache must be as idle as a freed one
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != b.dev) (void)hipSetDevice(b.dev);
+    const hipError_t e = hipDeviceSynchronize();
+    if (cur >= 0 && cur != b.dev) (void)hipSetDevice(cur);
+    if (e != hipSuccess) {
+        (void)hipFree(b.p);
+        return;
+    }
+    // at most half of the device's memory (DOTSOCP_DEVICE_CACHE_GB) stays in the cache: the oldest blocks go first
+    static const size_t cap = [] {
+        const char *g = getenv("DOTSOCP_DEVICE_CACHE_GB");
+        if (g && atof(g) >= 0) return (size_t)(atof(g) * 1e9);
+        size_t fr = 0, tot = 0;
+        return hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 2 : (size_t)64e9;
+    }();
+    std::vector<Block> evict;
+    {
+        std::lock_guard<std::mutex> lk(c_mu);
+        c_free.push_back(b);
+        size_t held = 0;
+        for (auto &x : c_free) held += x.bytes;
+        while (held > cap && !c_free.empty()) {
+            held -= c_free.front().bytes;
+            evict.push_back(c_free.front());
+            c_free.erase(c_free.begin());
+        }
+    }
+    for (auto &x : evict) {
+        if (x.dev != cur) (void)hipSetDevice(x.dev);
+        (void)hipFree(x.p);
+        if (cur >= 0 && x.dev != cur) (void)hipSetDevice(cur);
+    }
+}
+
 int guarded_malloc(void **p, size_t bytes) {
     *p = nullptr;
     if (!canary_enabled()) {
+        if (cache_enabled()) return cached_malloc(p, bytes);
         DS_HIP(hipMalloc(p, bytes));
         return 0;
     }
@@ -98,6 +233,10 @@ int guarded_malloc(void **p, size_t bytes) {
 
 void guarded_free(void *p) {
     if (!p) return;
+    if (!canary_enabled() && cache_enabled()) {
+        cached_free(p);
+        return;
+    }
     Rec r{};
     bool found = false;
     {

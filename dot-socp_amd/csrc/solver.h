@@ -14,9 +14,12 @@ namespace dotsocp {
 // Device allocations of the solver state go through guard.hip: with DOTSOCP_CANARY=1 in the environment every buffer
 // gets a guard band of NaN-pattern words on both sides, checked by canary_check() (finish(), destroy()) -- an
 // out-of-bounds WRITE of a tile kernel on a partial tile changes a guard word, an out-of-bounds READ pulls NaNs
-// into the iterates.  Without the variable the calls are plain hipMalloc / hipFree.
+// into the iterates.  Without the variable freed buffers are kept in a per-device cache and handed out again (guard.hip;
+// DOTSOCP_DEVICE_CACHE=0: plain hipMalloc / hipFree).
 int guarded_malloc(void **p, size_t bytes);
 void guarded_free(void *p);
+// the device block cache behind them (guard.hip): hipFree everything it holds; returns the bytes given back
+long long device_cache_release();
 // number of live buffers whose guard bands were overwritten (0 when the canaries are off); `report` receives a
 // description of the first few.  Synchronises the current device.
 int canary_check(std::string *report);

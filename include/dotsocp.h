@@ -47,6 +47,10 @@ const char *dotsocp_last_error(void);
 const char *dotsocp_version(void);
 /* number of visible HIP devices (0 when there is none; never fails) */
 int dotsocp_device_count(void);
+/* Device buffers of destroyed contexts are kept (per device) and reused by the next context that asks for buffers of
+ * their size: on this platform a hipMalloc that follows the release of tens of GB takes seconds.  This call returns
+ * them to the driver (bytes released); DOTSOCP_DEVICE_CACHE=0 in the environment disables the cache altogether. */
+dotsocp_i64 dotsocp_release_cache(void);
 
 /* ===================================================================================
  * B2 -- operator level, HOST pointers (replaces the reference MEX binaries)

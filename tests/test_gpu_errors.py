@@ -141,6 +141,38 @@ def test_driver_start_with_lazy_fields_equals_the_eager_one():
         np.testing.assert_allclose(np.asarray(y), np.asarray(x), rtol=1e-11, atol=1e-13 * np.abs(np.asarray(x)).max())
 
 
+def test_device_buffers_of_destroyed_contexts_are_reused():
+    """guard.hip's device block cache: the buffers of a destroyed context are handed out again (zero-filled) to the next
+    context of that size -- same results, bit for bit, as with fresh memory --, dotsocp_release_cache() returns them to the
+    driver, and a context of another size gets by without them."""
+    from oracle import driver as OD
+    from oracle.examples import get_example_2d
+    L = capi.lib()
+    L.dotsocp_release_cache()
+    o = OD.default_opts(dict(tol=0.0, maxit=25), "inPALM")
+
+    def solve(n, nt):
+        rho0, rho1 = get_example_2d("example1", n, n)
+        var, model = D.initialize(rho0, rho1, nt)
+        D.InitialScaling(var, model, True, None, dim=2)
+        hist, sigma = D.solver_socp_inPALM(var, o, model)
+        return var, hist, sigma
+
+    a, ha, sa = solve(40, 12)                        # fresh memory; its buffers go into the cache on destroy
+    b, hb, sb = solve(40, 12)                        # ... and serve this context
+    held = L.dotsocp_release_cache()
+    assert held > 8 * 40 * 40 * 12 * 27              # at least the state arrays came back
+    assert L.dotsocp_release_cache() == 0
+    c, hc, sc = solve(40, 12)                        # fresh again
+    d, hd, sd = solve(24, 8)                         # another size next to cached blocks that do not fit
+    assert sa == sb == sc
+    for f in ("phi", "q", "z", "alpha", "beta"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)) and np.array_equal(getattr(a, f), getattr(c, f))
+    assert np.array_equal(ha["kkt"], hb["kkt"]) and np.array_equal(ha["kkt"], hc["kkt"])
+    assert np.all(np.isfinite(d.phi)) and hd["len"] == ha["len"]
+    assert L.dotsocp_release_cache() > 0
+
+
 def test_variant_restrictions():
     L = capi.lib()
     o = _opts()
