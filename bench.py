@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -365,6 +366,156 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     hist, sigma = ctx.finish(download=False)
+
+    def emit(times, fallback_note=None):
+        """build and print the JSON line (rank 0) from the timed pass's figures and the phase timers `times`"""
+        # per-launch sizes of THIS rank's slab (the whole grid at N = 1)
+        t0s, t1s = D.capi.slab_range(nt, share, share // 2) if share else D.capi.slab_range(nt, world, rank)
+        ntl = t1s - t0s
+        ncl = ntl if t1s < nt else ntl - 1
+        Nz = ny * nx * ncl
+        Nq = Nz + (ny * (nx - 1) + (ny - 1) * nx) * (ncl + 1)
+        # Dominant kernel: the fused cone kernel in its steady-state mode (deferred multiplier update +
+        # cone projection + adjoint gather).  Algorithmic bytes per launch (SURVEY.md 8d, DESIGN.md):
+        # beta in + beta out (20 Nz) + q^{k-1}, q^k in (2 Nq) + adjoint sums out (Nq), fp64.
+        if args.method == "acc-ADMM":
+            # multiplier + z-step + Halpern step of z, beta + next adjoint sums: z, beta, anchors in, z, beta out
+            kname, (proj_ms, proj_n) = "k_acc_cone<1,4> (multiplier + projection + Halpern + gather)", times["acc_cone"]
+            alg_bytes = 8.0 * (60 * Nz + 2 * Nq)
+        elif args.method == "PALM" and times["cone_fused_b"][1] > 0:
+            # one pass over beta per iteration: beta in + out, q~^{k-1}, q^k, q~^k in, two adjoint gathers out
+            kname, (proj_ms, proj_n) = "k_cone_fused<5,4> (beta update + cone projection + two adjoint gathers)", times["cone_fused_b"]
+            alg_bytes = 8.0 * (20 * Nz + 5 * Nq)
+        elif args.method == "PALM":
+            kname, (proj_ms, proj_n) = "k_cone_fused<0,4> (cone projection + adjoint gather)", times["cone_fused_a"]
+            alg_bytes = 8.0 * (10 * Nz + 2 * Nq)
+        elif times["cone_fused_b"][1] > 0:
+            kname, (proj_ms, proj_n) = "k_cone_fused<1,4> (beta update + cone projection + adjoint gather)", times["cone_fused_b"]
+            alg_bytes = 8.0 * (20 * Nz + 3 * Nq)
+        else:                                     # DOTSOCP_FUSED=0: plain projection kernel, beta in + q in + z out
+            kname, (proj_ms, proj_n) = "k_cone_march<0> (cone projection)", times["cone_proj"]
+            alg_bytes = 8.0 * (20 * Nz + Nq)
+        # time-slab mode: the cone pass of an iteration runs as two timed intervals (the chunks in front of the last one, then the
+        # last chunk, which alone reads the q halo): the average interval covers half of the slab's cells
+        slab_mode = world > 1 or args.nslabs > 1 or bool(share)
+        cone_parts = 2 if (slab_mode and ncl >= 12 and os.environ.get("DOTSOCP_OVERLAP", "1") != "0"
+                           and args.method in ("inPALM", "ALG2")) else 1
+        alg_bytes /= cone_parts
+        achieved = alg_bytes / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
+        # HBM bytes of the dominant kernel by the PMC counters: a figure of the builder's profiling run of THIS round's build
+        # (profiles/cone_proj_traffic.json, separate --pmc FETCH_SIZE / WRITE_SIZE passes), not of this run -- tagged as such,
+        # and left out when the record is from another round, grid, method or kernel
+        traffic, traffic_source = None, None
+        tf = os.path.join(ROOT, "profiles", "cone_proj_traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf))
+                if (rec.get("grid") == [ny, nx, nt] and args.method in ("inPALM", "ALG2") and rec.get("round") == BUILD_ROUND
+                        and kname.startswith(rec.get("kernel", "?").replace(" ", "")[:14])):
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = (f"profiles/cone_proj_traffic.json (builder's rocprofv3 PMC passes of round {rec.get('round')}, "
+                                      f"commit {rec.get('commit', 'n/a')}; not a counter of this run)")
+            except Exception:
+                traffic = None
+        # the other kernels of a plain iteration, so that the line shows the one furthest below the roofline; phase timers
+        # (HIP events on the launch stream) with the algorithmic bytes of DESIGN.md section 3; Nphi = nodes of this slab
+        Nphi = ny * nx * ntl
+
+        def krow(name, nbytes, key, launches_per_phase=1):
+            ms, n = times[key]
+            if ms <= 0 or n <= 0:
+                return None
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            return {"name": name, "algorithmic_bytes": nbytes, "avg_ms": round(ms, 4), "launches_per_phase": launches_per_phase,
+                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        kernels = [r for r in (
+            krow(kname, alg_bytes, {"acc-ADMM": "acc_cone", "PALM": "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_fused_a"}.get(args.method, "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_proj")),
+            krow("k_qstep_rhs (A phi, q-step, alpha update, next rhs)", 8.0 * (3 * Nphi + 4 * Nq), "qstep"),
+            krow("Poisson solve: y, x forward, fused t pass, x, y inverse (five launches; k_dct_* / k_pfa_*)", 8.0 * 10 * Nphi,
+                 "poisson", 5),
+        ) if r]
+        out = {
+            "metric": "ADMM iters/sec on NxNxT dot2d staggered grid at 1/2/4/8 MI355X",
+            "value": args.steps / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} {ny}x{nx}x{nt} Gaussian-to-Gaussian (Example 5.1), " + {
+                           "inPALM": "inPALM tau=1.9", "ALG2": "ALG2 tau=1.0", "PALM": "PALM tau=1.9",
+                           "acc-ADMM": "acc-ADMM (Halpern, rho=2, restart=100)"}[args.method] + ", levelN=1",
+                       "grid": [ny, nx, nt],
+                       "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
+                       # which kind of box this run landed on: device-to-device copy rate of a 1 GiB buffer measured right
+                       # before the warm-up (read + write bytes / time; the pool's two kinds differ by ~10 % in every HBM-bound kernel)
+                       "box_copy_gbs": box_copy_gbs,
+                       # the timed region runs with the library's per-phase HIP events switched on (they feed roofline and
+                       # kernel_ms); DOTSOCP_BENCH_NOPROF=1 times it without them
+                       "per_phase_hip_events_in_timed_region": not bool(os.environ.get("DOTSOCP_BENCH_NOPROF")) and not two_pass,
+                       "parallelism": (f"rank share: slab {share // 2} of {share} time slabs on 1 GPU, neighbour messages as local "
+                                       f"copies (timing only, not a valid solve)") if share else
+                                      ("1 GPU" if world == 1 else f"{world} time slabs")},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": proj_ms, "launches": proj_n,
+                         # SURVEY.md 8d's narrower figure for the projection alone, 8 (20 Nz + Nq): what the same launch scores
+                         # if only beta in, q in and z out are counted (this kernel also reads q^{k-1} and writes the adjoint sums)
+                         "frac_projection_only": (8.0 * (20 * Nz + Nq) / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if proj_ms > 0 else 0.0,
+                         "kernels": kernels},
+            "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
+        }
+        if two_pass and not share:
+            out["config"]["timed_pass"] = ("without per-phase HIP events (they cost a rank's 1.7 ms iteration 4-5 %); kernel_ms / roofline "
+                                           "come from a second, untimed run of the same W + K iterations with them")
+        if share:
+            out["rank_share"] = {"n": share, "slab": share // 2, "time_nodes": int(ntl),
+                                 "kernel_ms_sum": round(sum(v[0] * v[1] for v in times.values()) / max(args.steps, 1), 4),
+                                 "full_grid_ms_per_step": full_ms,
+                                 "ceiling": (full_ms / (dt / args.steps * 1e3)) if full_ms else None,
+                                 "ceiling_note": ("T(full grid) / T(this rank's share), both timed in THIS run (same process, same box, same "
+                                                  "W and K, no per-phase events): the compute-only ceiling of the N-GPU strong-scaling curve")
+                                 if full_ms else "the full grid does not fit one GPU: the share is timed alone",
+                                 "timed_pass": "without per-phase HIP events; kernel_ms / roofline come from a second run of the same W + K "
+                                               "iterations with them" if two_pass else "with per-phase HIP events",
+                                 "note": "kernel_ms_sum = per-iteration sum of the phase timers (HIP events on the launch streams; "
+                                         "phases on the second stream overlap the main one); ms_per_step - overlap-free kernel time = "
+                                         "launch / dependency chain + host"}
+        if slab_mode:
+            out["roofline"]["note"] = (f"time slabs: the cone pass of an iteration is {cone_parts} timed interval(s) (chunks of time cells, "
+                                       "one launch each); bytes and time are per interval; the N = 1 line is the kernel's roofline figure")
+        if fallback_note:
+            out["config"]["timed_pass"] = fallback_note
+        if rank == 0:
+            if not args.no_cpu_baseline and world == 1 and args.method == "inPALM" and not share:
+                out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
+            print(json.dumps(out), flush=True)
+    phase_keys = ("rhs", "poisson", "cone_fused_a", "cone_fused_b", "cone_proj", "qstep", "beta", "materialise", "kkt", "comm",
+                  "interp", "acc_cone", "acc_gather", "qstep_first", "transpose")
+    emit_lock, emitted = threading.Lock(), []
+    watchdog = None
+    if two_pass and dist is not None:
+        # several real ranks: should the instrumented pass (a second communicator, the same iterations again) ever hang, the
+        # timed pass's result is not lost with it -- after DOTSOCP_BENCH_PASS2_LIMIT seconds rank 0 prints the line without
+        # phase timers and every rank leaves
+        def bail():
+            with emit_lock:
+                if not emitted:
+                    emitted.append(True)
+                    emit({k: (0.0, 0) for k in phase_keys},
+                         "the instrumented second pass did not finish in time: kernel_ms and roofline are empty, value is "
+                         "the timed pass's (run without per-phase HIP events)")
+                    os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("DOTSOCP_BENCH_PASS2_LIMIT", "240")), bail)
+        watchdog.daemon = True
+        watchdog.start()
     if two_pass:
         # the instrumented pass: the SAME W + K iterations again in a context of its own (its own communicator), per-phase
         # events on during the K -- untimed; `kernel_ms` and `roofline` come from here
@@ -376,137 +527,15 @@ def main():
         assert ctx.run(args.steps) == args.steps
         fence()
         ctx.finish(download=False)
-    times = {k: ctx.kernel_time(k) for k in ("rhs", "poisson", "cone_fused_a", "cone_fused_b", "cone_proj",
-                                             "qstep", "beta", "materialise", "kkt", "comm", "interp", "acc_cone",
-                                             "acc_gather", "qstep_first", "transpose")}
+    times = {k: ctx.kernel_time(k) for k in phase_keys}
     ctx.close()
+    if watchdog is not None:
+        watchdog.cancel()
+    with emit_lock:
+        if not emitted:
+            emitted.append(True)
+            emit(times)
 
-    # per-launch sizes of THIS rank's slab (the whole grid at N = 1)
-    t0s, t1s = D.capi.slab_range(nt, share, share // 2) if share else D.capi.slab_range(nt, world, rank)
-    ntl = t1s - t0s
-    ncl = ntl if t1s < nt else ntl - 1
-    Nz = ny * nx * ncl
-    Nq = Nz + (ny * (nx - 1) + (ny - 1) * nx) * (ncl + 1)
-    # Dominant kernel: the fused cone kernel in its steady-state mode (deferred multiplier update +
-    # cone projection + adjoint gather).  Algorithmic bytes per launch:
-    # beta in + beta out (20 Nz) + q^{k-1}, q^k in (2 Nq) + adjoint sums out (Nq), fp64.
-    if args.method == "acc-ADMM":
-        # multiplier + z-step + Halpern step of z, beta + next adjoint sums: z, beta, anchors in, z, beta out
-        kname, (proj_ms, proj_n) = "k_acc_cone<1,4> (multiplier + projection + Halpern + gather)", times["acc_cone"]
-        alg_bytes = 8.0 * (60 * Nz + 2 * Nq)
-    elif args.method == "PALM" and times["cone_fused_b"][1] > 0:
-        # one pass over beta per iteration: beta in + out, q~^{k-1}, q^k, q~^k in, two adjoint gathers out
-        kname, (proj_ms, proj_n) = "k_cone_fused<5,4> (beta update + cone projection + two adjoint gathers)", times["cone_fused_b"]
-        alg_bytes = 8.0 * (20 * Nz + 5 * Nq)
-    elif args.method == "PALM":
-        kname, (proj_ms, proj_n) = "k_cone_fused<0,4> (cone projection + adjoint gather)", times["cone_fused_a"]
-        alg_bytes = 8.0 * (10 * Nz + 2 * Nq)
-    elif times["cone_fused_b"][1] > 0:
-        kname, (proj_ms, proj_n) = "k_cone_fused<1,4> (beta update + cone projection + adjoint gather)", times["cone_fused_b"]
-        alg_bytes = 8.0 * (20 * Nz + 3 * Nq)
-    else:                                     # DOTSOCP_FUSED=0: plain projection kernel, beta in + q in + z out
-        kname, (proj_ms, proj_n) = "k_cone_march<0> (cone projection)", times["cone_proj"]
-        alg_bytes = 8.0 * (20 * Nz + Nq)
-    # time-slab mode: the cone pass of an iteration runs as two timed intervals (the chunks in front of the last one, then the
-    # last chunk, which alone reads the q halo): the average interval covers half of the slab's cells
-    slab_mode = world > 1 or args.nslabs > 1 or bool(share)
-    cone_parts = 2 if (slab_mode and ncl >= 12 and os.environ.get("DOTSOCP_OVERLAP", "1") != "0"
-                       and args.method in ("inPALM", "ALG2")) else 1
-    alg_bytes /= cone_parts
-    achieved = alg_bytes / (proj_ms * 1e-3) / 1e9 if proj_ms > 0 else 0.0
-    # HBM bytes of the dominant kernel by the PMC counters: a figure of the builder's profiling run of THIS round's build
-    # (profiles/cone_proj_traffic.json, separate --pmc FETCH_SIZE / WRITE_SIZE passes), not of this run -- tagged as such,
-    # and left out when the record is from another round, grid, method or kernel
-    traffic, traffic_source = None, None
-    tf = os.path.join(ROOT, "profiles", "cone_proj_traffic.json")
-    if os.path.exists(tf):
-        try:
-            rec = json.load(open(tf))
-            if (rec.get("grid") == [ny, nx, nt] and args.method in ("inPALM", "ALG2") and rec.get("round") == BUILD_ROUND
-                    and kname.startswith(rec.get("kernel", "?").replace(" ", "")[:14])):
-                traffic = rec.get("hbm_bytes_per_launch")
-                traffic_source = (f"profiles/cone_proj_traffic.json (builder's rocprofv3 PMC passes of round {rec.get('round')}, "
-                                  f"commit {rec.get('commit', 'n/a')}; not a counter of this run)")
-        except Exception:
-            traffic = None
-    # the other kernels of a plain iteration, so that the line shows the one furthest below the roofline; phase timers
-    # (HIP events on the launch stream) with the algorithmic bytes of DESIGN.md section 3; Nphi = nodes of this slab
-    Nphi = ny * nx * ntl
-
-    def krow(name, nbytes, key, launches_per_phase=1):
-        ms, n = times[key]
-        if ms <= 0 or n <= 0:
-            return None
-        gbs = nbytes / (ms * 1e-3) / 1e9
-        return {"name": name, "algorithmic_bytes": nbytes, "avg_ms": round(ms, 4), "launches_per_phase": launches_per_phase,
-                "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-
-    kernels = [r for r in (
-        krow(kname, alg_bytes, {"acc-ADMM": "acc_cone", "PALM": "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_fused_a"}.get(args.method, "cone_fused_b" if times["cone_fused_b"][1] > 0 else "cone_proj")),
-        krow("k_qstep_rhs (A phi, q-step, alpha update, next rhs)", 8.0 * (3 * Nphi + 4 * Nq), "qstep"),
-        krow("Poisson solve: y, x forward, fused t pass, x, y inverse (five launches; k_dct_* / k_pfa_*)", 8.0 * 10 * Nphi,
-             "poisson", 5),
-    ) if r]
-    out = {
-        "metric": "ADMM iters/sec on NxNxT dot2d staggered grid at 1/2/4/8 MI355X",
-        "value": args.steps / dt,
-        "unit": "iterations/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload} {ny}x{nx}x{nt} Gaussian-to-Gaussian (Example 5.1), " + {
-                       "inPALM": "inPALM tau=1.9", "ALG2": "ALG2 tau=1.0", "PALM": "PALM tau=1.9",
-                       "acc-ADMM": "acc-ADMM (Halpern, rho=2, restart=100)"}[args.method] + ", levelN=1",
-                   "grid": [ny, nx, nt],
-                   "kkt_checks_in_timed_region": int(np.sum(hist["iter"] > args.warmup)),
-                   # which kind of box this run landed on: device-to-device copy rate of a 1 GiB buffer measured right
-                   # before the warm-up (read + write bytes / time; the pool's two kinds differ by ~10 % in every HBM-bound kernel)
-                   "box_copy_gbs": box_copy_gbs,
-                   # the timed region runs with the library's per-phase HIP events switched on (they feed roofline and
-                   # kernel_ms); DOTSOCP_BENCH_NOPROF=1 times it without them
-                   "per_phase_hip_events_in_timed_region": not bool(os.environ.get("DOTSOCP_BENCH_NOPROF")) and not two_pass,
-                   "parallelism": (f"rank share: slab {share // 2} of {share} time slabs on 1 GPU, neighbour messages as local "
-                                   f"copies (timing only, not a valid solve)") if share else
-                                  ("1 GPU" if world == 1 else f"{world} time slabs")},
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": proj_ms, "launches": proj_n,
-                     # SURVEY.md 8d's narrower figure for the projection alone, 8 (20 Nz + Nq): what the same launch scores
-                     # if only beta in, q in and z out are counted (this kernel also reads q^{k-1} and writes the adjoint sums)
-                     "frac_projection_only": (8.0 * (20 * Nz + Nq) / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if proj_ms > 0 else 0.0,
-                     "kernels": kernels},
-        "kernel_ms": {k: round(v[0], 4) for k, v in times.items()},
-    }
-    if two_pass and not share:
-        out["config"]["timed_pass"] = ("without per-phase HIP events (they cost a rank's 1.7 ms iteration 4-5 %); kernel_ms / roofline "
-                                       "come from a second, untimed run of the same W + K iterations with them")
-    if share:
-        out["rank_share"] = {"n": share, "slab": share // 2, "time_nodes": int(ntl),
-                             "kernel_ms_sum": round(sum(v[0] * v[1] for v in times.values()) / max(args.steps, 1), 4),
-                             "full_grid_ms_per_step": full_ms,
-                             "ceiling": (full_ms / (dt / args.steps * 1e3)) if full_ms else None,
-                             "ceiling_note": ("T(full grid) / T(this rank's share), both timed in THIS run (same process, same box, same "
-                                              "W and K, no per-phase events): the compute-only ceiling of the N-GPU strong-scaling curve")
-                             if full_ms else "the full grid does not fit one GPU: the share is timed alone",
-                             "timed_pass": "without per-phase HIP events; kernel_ms / roofline come from a second run of the same W + K "
-                                           "iterations with them" if two_pass else "with per-phase HIP events",
-                             "note": "kernel_ms_sum = per-iteration sum of the phase timers (HIP events on the launch streams; "
-                                     "phases on the second stream overlap the main one); ms_per_step - overlap-free kernel time = "
-                                     "launch / dependency chain + host"}
-    if slab_mode:
-        out["roofline"]["note"] = (f"time slabs: the cone pass of an iteration is {cone_parts} timed interval(s) (chunks of time cells, "
-                                   "one launch each); bytes and time are per interval; the N = 1 line is the kernel's roofline figure")
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and args.method == "inPALM" and not share:
-            out["cpu_baseline"] = cpu_baseline(args.workload, ny, nx, nt, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

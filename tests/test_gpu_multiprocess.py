@@ -216,6 +216,30 @@ def test_bench_under_torchrun_rehearsal(world):
     assert rec["roofline"]["launches"] > 0 and rec["kernel_ms"]["comm"] > 0
 
 
+def test_bench_line_survives_a_second_pass_that_does_not_finish():
+    """bench.py with several ranks times a pass without per-phase events and fills kernel_ms / roofline from a second,
+    untimed pass on a communicator of its own.  Should that pass ever hang on real hardware, a watchdog prints the line with
+    the timed pass's value and empty phase timers and every rank leaves: here the limit is zero, so it always fires."""
+    import json
+    import socket
+    _build_fake()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DOTSOCP_RCCL_LIB=FAKE_SO, DOTSOCP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               DOTSOCP_BENCH_PASS2_LIMIT="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--no-cpu-baseline", "--grid", "64", "48", "16"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 12 and np.isfinite(rec["value"]) and rec["value"] > 0
+    assert "did not finish" in rec["config"]["timed_pass"] and rec["kernel_ms"]["comm"] == 0
+
+
 @pytest.mark.parametrize("world", [2])
 def test_bench_self_launch_rehearsal(world):
     """`python bench.py --gpus N` with NO outer launcher: bench.py starts its own rank processes (self_launch),
