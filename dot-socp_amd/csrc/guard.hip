@@ -233,10 +233,7 @@ int guarded_malloc(void **p, size_t bytes) {
 
 void guarded_free(void *p) {
     if (!p) return;
-    if (!canary_enabled() && cache_enabled()) {
-        cached_free(p);
-        return;
-    }
+    // which way a buffer goes back is decided by how it was allocated, not by the environment at the time of the free
     Rec r{};
     bool found = false;
     {
@@ -244,7 +241,9 @@ void guarded_free(void *p) {
         auto it = g_live.find(p);
         if (it != g_live.end()) { r = it->second; found = true; g_live.erase(it); }
     }
-    (void)hipFree(found ? (void *)r.base : p);
+    if (found) (void)hipFree((void *)r.base);
+    else if (cache_enabled()) cached_free(p);       // (a pointer the cache does not know is freed there)
+    else (void)hipFree(p);
 }
 
 int canary_check(std::string *report) {
