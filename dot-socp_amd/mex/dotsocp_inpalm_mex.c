@@ -43,7 +43,13 @@ static const double *sized(const mxArray *a, const dotsocp_problem *p, int field
     return pr;
 }
 
+/* The library keeps the device buffers of a finished call for the next call on a grid of that size (on this platform a
+ * hipMalloc that follows the release of tens of GB takes seconds); `clear mex` / MATLAB exit hands them back. */
+static void release_cache_at_exit(void) { (void)dotsocp_release_cache(); }
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    static int at_exit_set = 0;
+    if (!at_exit_set) { mexAtExit(release_cache_at_exit); at_exit_set = 1; }
     if (nrhs != 2 || !mxIsStruct(prhs[0]) || !mxIsStruct(prhs[1]))
         mexErrMsgIdAndTxt(ID, "usage: out = dotsocp_inpalm_mex(S, opts)");
     if (nlhs > 1) mexErrMsgIdAndTxt(ID, "one output");

@@ -36,6 +36,7 @@ static int g_atexit = 0;
 static void release_all(void) {           /* mexAtExit: `clear mex` must not strand full-grid HBM allocations */
     for (int i = 0; i < MAXH; ++i)
         if (g_levels[i].ctx) { dotsocp_destroy(g_levels[i].ctx); g_levels[i].ctx = NULL; }
+    (void)dotsocp_release_cache();        /* ... nor the buffers the library keeps for the next context of their size */
 }
 
 /* a full real double array of exactly dotsocp_field_len(p, field) elements, or a MATLAB error -- checked before the
