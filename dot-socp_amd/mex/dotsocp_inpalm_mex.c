@@ -124,7 +124,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     memset(&res, 0, sizeof res);
     /* var.time carries the reference's tic/toc columns (solver_socp_inPALM.m:339-341): per-step device times on */
     int rc = dotsocp_set_profiling(ctx, 1);
-    for (int i = 0; i < 6 && rc == 0; ++i) rc = dotsocp_upload(ctx, fields[i], in[i]);
+    /* the inPALM / ALG2 loop overwrites z before its first use (solver_socp_inPALM.m:199; the rescale block, the only other
+     * reader, needs it >= 10): with at least one iteration to run, S.z -- 10 of the 27 N doubles of the state -- stays home */
+    const int z_unread = method == DOTSOCP_METHOD_INPALM && o.maxit >= 1;
+    for (int i = 0; i < 6 && rc == 0; ++i)
+        if (!(z_unread && fields[i] == DOTSOCP_F_Z)) rc = dotsocp_upload(ctx, fields[i], in[i]);
     if (rc == 0 && p.weighted) rc = dotsocp_upload(ctx, DOTSOCP_F_WEIGHT, in[6]);
     if (rc == 0) rc = dotsocp_begin_method(ctx, &o, method, &acc);
     if (rc == 0) rc = dotsocp_run(ctx, -1, NULL);

@@ -46,14 +46,17 @@ class InPALMContext:
     """Stateful handle on one device-resident loop (create -> upload -> begin -> run* -> finish)."""
 
     def __init__(self, var, opts, model, weighted=False, device=0, nslabs=1, profiling=False, rccl=None,
-                 method="inPALM", warm_from=None, ngpu=None):
+                 method="inPALM", warm_from=None, ngpu=None, z_unread=False):
         """rccl = (unique_id_bytes, rank, world): one process per GPU, this process owns time slab
         `rank`; var / model then hold the LOCAL slab of every field (model.nt stays the global nt).
         method: which loop file of the reference runs ("inPALM"/"ALG2" by opts.tau, "PALM", "acc-ADMM").
         warm_from: the finished context of the previous (coarser) multilevel level: phi, q, alpha, z, beta are
         then produced on the device by jump_nextLevel.m's transfer instead of being uploaded from `var`.
         ngpu: single-process multi-GPU (dotsocp_create_multi): that many time slabs, slab r on device
-        (device + r) mod #devices; nslabs (diagnostic) keeps all slabs on `device`."""
+        (device + r) mod #devices; nslabs (diagnostic) keeps all slabs on `device`.
+        z_unread: the caller will run at least one iteration of the inPALM / ALG2 loop, which overwrites z before its first
+        use (solver_socp_inPALM.m:199; the rescale block, the only other reader, needs it >= 10): var.z is not uploaded --
+        10 of the 27 N doubles of the state (tests/test_gpu_solver.py::test_iterations_from_a_random_state)."""
         L = capi.lib()
         self.method = method
         one_d = not hasattr(model, "ny")
@@ -77,8 +80,9 @@ class InPALMContext:
                 buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(uid))
                 capi.check(L.dotsocp_attach_rccl(self._ctx, buf, int(rk), int(wd)))
             # a field left as None keeps the device default (zeros), e.g. z, beta, q, alpha of a cold start
+            skip_z = z_unread and METHODS[method] == capi.METHOD_INPALM and int(_get(opts, "maxit")) >= 1
             state = () if warm_from is not None else ((capi.F_PHI, var.phi), (capi.F_Q, var.q), (capi.F_ALPHA, var.alpha),
-                                                      (capi.F_Z, var.z), (capi.F_BETA, var.beta))
+                                                      (capi.F_Z, None if skip_z else var.z), (capi.F_BETA, var.beta))
             for f, a in state:
                 if a is not None:
                     self.upload(f, a)
@@ -200,7 +204,7 @@ class InPALMContext:
 def solver_socp_inPALM(var, opts, model, device=0, nslabs=1):
     """[runHist, sigma] = solver_socp_inPALM(var, opts, model); `var` is mutated in place.
     nslabs > 1 runs the multi-GPU time-slab algorithm with all slabs on this one device."""
-    ctx = InPALMContext(var, opts, model, weighted=False, device=device, nslabs=nslabs)
+    ctx = InPALMContext(var, opts, model, weighted=False, device=device, nslabs=nslabs, z_unread=True)
     try:
         ctx.run(-1)
         return ctx.finish()
@@ -210,7 +214,7 @@ def solver_socp_inPALM(var, opts, model, device=0, nslabs=1):
 
 def solver_wsocp_inPALM(var, opts, model, device=0, nslabs=1):
     """[runHist, sigma] = solver_wsocp_inPALM(var, opts, model) (model.weight required)."""
-    ctx = InPALMContext(var, opts, model, weighted=True, device=device, nslabs=nslabs)
+    ctx = InPALMContext(var, opts, model, weighted=True, device=device, nslabs=nslabs, z_unread=True)
     try:
         ctx.run(-1)
         return ctx.finish()

@@ -137,8 +137,8 @@ def test_iterations_from_a_random_state(case, K, nslabs, request):
     """The steps of ONE iteration in isolation from any trajectory: phi, q, alpha and beta are
     random -- every term of the q-step's right-hand side, of its diagonal, of the multiplier updates and of the KKT sums
     is generic, none vanishes as in the all-zero start of initialize.m -- and one to three iterations with a KKT check in
-    each are compared with the oracle field by field.  (z comes in as zeros: solver_socp_inPALM.m:199 overwrites it before
-    its first use.)  nslabs > 1: the same on time slabs, whose very first halo exchanges then carry generic layers.
+    each are compared with the oracle field by field (z is random too: solver_socp_inPALM.m:199 overwrites it before its
+    first use, so it must not matter).  nslabs > 1: the same on time slabs, whose very first halo exchanges then carry generic layers.
     beta is zero where the cone row has no edge (the slots mexBFd leaves unwritten at the domain boundary): the reference
     never makes them non-zero, and compute_kkt_dot_complement reads what the projection of :240 left in those slots of
     the shared temporary z2 (:242 does not overwrite them) -- stale data the device, which builds z2 in registers, does
@@ -162,6 +162,7 @@ def test_iterations_from_a_random_state(case, K, nslabs, request):
     gvar, gmodel, go = _gpu_level(rho0, rho1, nt, opts, "inPALM", weight)
     start = {"phi": rng.standard_normal(ovar.phi.shape), "q": 0.3 * rng.standard_normal(ovar.q.shape),
              "alpha": 0.5 * rng.standard_normal(ovar.alpha.shape),
+             "z": np.asfortranarray(0.6 * rng.standard_normal(ovar.z.shape)),      # read by nobody (:199 overwrites it first)
              "beta": np.asfortranarray(0.4 * rng.standard_normal(ovar.beta.shape))}
     from oracle import mexops
     probe = np.full(ovar.beta.shape, np.nan, order="F")
@@ -171,6 +172,7 @@ def test_iterations_from_a_random_state(case, K, nslabs, request):
         mexops.mexBFd(probe, start["q"], nt, rho0.shape[1], rho0.shape[0])
     assert 0 < np.isnan(probe).sum() < probe.size // 4
     start["beta"][np.isnan(probe)] = 0.0
+    start["z"][np.isnan(probe)] = 0.0
     for v in (ovar, gvar):
         for f, a in start.items():
             setattr(v, f, a.copy(order="F"))

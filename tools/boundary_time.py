@@ -25,7 +25,7 @@ for x in (var.phi, var.q, var.alpha, var.z, var.beta, model.c):
 gb = sum(x.nbytes for x in (var.phi, var.q, var.alpha, var.z, var.beta)) / 1e9
 opts = dict(tau=1.9, sigma=1.0, tol=0.0, maxit=K, scaling=True, ifCheckStepByStep=False, time_limit=1e9)
 t0 = time.perf_counter()
-ctx = D.InPALMContext(var, opts, model)
+ctx = D.InPALMContext(var, opts, model, z_unread=True)     # as solver_socp_inPALM / the MEX gateway do: z is overwritten before its first use
 ctx.synchronize()
 t1 = time.perf_counter()
 assert ctx.run(-1) == K
@@ -37,8 +37,9 @@ t3 = time.perf_counter()
 ctx.close()
 t4 = time.perf_counter()
 del held
-print(f"B1 with host buffers, {ny}x{nx}x{nt}, K = {K}: state {gb:.1f} GB each way; create + upload {t1 - t0:.2f} s "
-      f"({(gb + model.c.nbytes / 1e9) / (t1 - t0):.1f} GB/s), loop {t2 - t1:.2f} s ({K / (t2 - t1):.1f} it/s), finish + download "
+up = gb + model.c.nbytes / 1e9 - var.z.nbytes / 1e9
+print(f"B1 with host buffers, {ny}x{nx}x{nt}, K = {K}: state {gb:.1f} GB (up: {up:.1f} GB, z stays home); create + upload {t1 - t0:.2f} s "
+      f"({up / (t1 - t0):.1f} GB/s), loop {t2 - t1:.2f} s ({K / (t2 - t1):.1f} it/s), finish + download "
       f"{t3 - t2:.2f} s ({gb / (t3 - t2):.1f} GB/s), destroy {t4 - t3:.2f} s; whole call {t4 - t0:.2f} s = "
       f"{K / (t4 - t0):.1f} it/s including the transfers; host threads {os.environ.get('DOTSOCP_HOST_COPY_THREADS', 'default')}")
 assert np.all(np.isfinite(hist["kkt"]))
